@@ -1,0 +1,178 @@
+"""Pins oracle/uml_oracle.py (the CPU restatement) against golden vectors that
+oracle/make_golden.py produced by running the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import uml_oracle as O
+
+STEP_CASES = ["clip_d64_c10", "clip_d512_c100", "clip_d128_c1000", "lin_d96_c37",
+              "mlp_d48_t64_c10", "mlp_d96_t160_c20"]
+
+
+def _state_from_step(g):
+    learn = "g_img_scale" in g.files
+    return O.HeadState(g["w_head"].copy(), g["w_proj"].copy() if "w_proj" in g.files else None,
+                       float(g["scale_img"]), float(g["scale_txt"]), learn)
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_single_step_logits_loss_grads(case):
+    g = load_golden("step_" + case)
+    st = _state_from_step(g)
+    so = O.step_grads(st, g["x_img"], g["y_img"], g["x_txt"], g["y_txt"], float(g["alpha"]))
+    # north_star tolerance: logits / loss within 1e-4 (fp32)
+    np.testing.assert_allclose(so.zi, g["img_logits"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(so.zt, g["txt_logits"], atol=1e-4, rtol=0)
+    assert abs(so.loss_img - float(g["loss_img"])) < 1e-4
+    assert abs(so.loss_txt - float(g["loss_txt"])) < 1e-4
+    assert abs(so.acc_img - float(g["acc_img"])) < 1e-6
+    assert abs(so.acc_txt - float(g["acc_txt"])) < 1e-6
+    gs = np.abs(g["g_head"]).max()
+    np.testing.assert_allclose(so.grads["w_head"], g["g_head"], atol=2e-5 * gs, rtol=1e-4)
+    np.testing.assert_allclose(so.g_head_img, g["g_head_img"], atol=2e-5 * gs, rtol=1e-4)
+    np.testing.assert_allclose(so.g_head_txt, g["g_head_txt"], atol=2e-5 * gs, rtol=1e-4)
+    if "g_proj" in g.files:
+        np.testing.assert_allclose(so.grads["w_proj"], g["g_proj"], atol=2e-5 * np.abs(g["g_proj"]).max(), rtol=1e-4)
+    if "g_img_scale" in g.files:
+        assert abs(float(so.grads["img_scale"]) - float(g["g_img_scale"])) < 1e-5
+        assert abs(float(so.grads["txt_scale"]) - float(g["g_txt_scale"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["cos_lin", "cos_const", "lin_lin", "cos_nowarm"])
+def test_lr_schedule_matches_reference_builders(tag):
+    g = load_golden("lr_traces")
+    lr, warm, max_iter, wlr = g[tag + "_cfg"]
+    kind = "linear" if tag.startswith("lin") else "cosine"
+    wtype = {"cos_lin": "linear", "cos_const": "constant", "lin_lin": "linear", "cos_nowarm": None}[tag]
+    s = O.LRSchedule(lr, kind, int(warm), int(max_iter), wtype, None if wlr < 0 else wlr)
+    ref = g[tag]
+    tab = s.table(len(ref))
+    np.testing.assert_allclose(tab, ref, rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(tab, g[tag + "_last"], rtol=1e-12, atol=1e-18)
+
+
+def test_lr_schedule_known_answers():
+    # SURVEY.md 8(a9) probed known answers for (lr=1e-3, warmup 50, min 1e-5, max_iter 12800)
+    t = O.LRSchedule(1e-3, "cosine", 50, 12800, "linear", 1e-5).table(12800)
+    assert t[0] == 1e-5 and abs(t[1] - 2e-5) < 1e-15 and abs(t[2] - 4e-5) < 1e-15 and abs(t[3] - 6e-5) < 1e-15
+    assert abs(t[49] - 9.8e-4) < 1e-12 and t[50] == 1e-3
+    assert abs(t[51] - 9.99999985e-4) < 1e-11
+    assert abs(t[6400] - 5.0613577e-4) < 1e-10
+
+
+def test_lr_schedule_argument_errors():
+    with pytest.raises(ValueError):
+        O.LRSchedule(1e-3, "step", 0, 10)
+    with pytest.raises(ValueError):
+        O.LRSchedule(1e-3, "cosine", 5, 10, "exp", 1e-5)
+
+
+def _replay_traj(tag, optim, sched_kind, wtype):
+    g = load_golden("traj_" + tag)
+    lr, wd, warm, max_iter, wlr, alpha = g["hyper"]
+    learn = tag.endswith("mlp")
+    st = O.HeadState(g["w_head0"].copy(), g["w_proj0"].copy() if "w_proj0" in g.files else None,
+                     1.0, 1.0, learn)
+    opt = O.OptState(optim, float(wd))
+    sched = O.LRSchedule(lr, sched_kind, int(warm), int(max_iter), wtype, wlr)
+    steps = g["x_img"].shape[0]
+    for k in range(steps):
+        so = O.step_grads(st, g["x_img"][k], g["y_img"][k], g["x_txt"][k], g["y_txt"][k], float(alpha))
+        assert abs(so.loss_img - g["loss_img"][k]) < 1e-4, k
+        assert abs(so.loss_txt - g["loss_txt"][k]) < 1e-4, k
+        cur = sched.get_last_lr()
+        assert abs(cur - g["lr"][k]) <= 1e-12 * max(1.0, abs(cur)), k
+        O.optimizer_step(st, so.grads, opt, cur)
+        sched.step()
+        key = f"w_head_after_{k}"
+        if key in g.files:
+            np.testing.assert_allclose(st.w_head, g[key], atol=2e-6, rtol=2e-5, err_msg=key)
+            if st.w_proj is not None:
+                np.testing.assert_allclose(st.w_proj, g[f"w_proj_after_{k}"], atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(opt.m["w_head"], g["m_head_final"], atol=1e-7, rtol=1e-3)
+    if "v_head_final" in g.files:
+        np.testing.assert_allclose(opt.v["w_head"], g["v_head_final"], atol=1e-10, rtol=1e-3)
+    if learn:
+        assert abs(st.img_scale - float(g["img_scale_final"])) < 1e-5
+        assert abs(st.txt_scale - float(g["txt_scale_final"])) < 1e-5
+
+
+def test_traj_adamw():
+    _replay_traj("adamw_lin", "adamw", "cosine", "linear")
+
+
+def test_traj_sgd():
+    _replay_traj("sgd_lin", "sgd", "cosine", "linear")
+
+
+def test_traj_adam():
+    _replay_traj("adam_lin", "adam", "linear", "constant")
+
+
+def test_traj_adamw_mlp_learnable_temp():
+    _replay_traj("adamw_mlp", "adamw", "cosine", "linear")
+
+
+def test_zero_shot_and_text_reductions():
+    g = load_golden("text_side")
+    w = O.zero_shot_weights(g["feats"], g["labels"], int(g["num_classes"]))
+    np.testing.assert_allclose(w, g["zero_shot_w"], atol=1e-6)
+    assert np.all(w[1] == 0) and np.all(w[7] == 0)          # classes without text stay 0
+    af, al = O.text_average(g["feats"], g["labels"])
+    np.testing.assert_allclose(af, g["avg_feats"], atol=1e-6)
+    np.testing.assert_array_equal(al, g["avg_labels"])
+    torch.manual_seed(int(g["shot_seed"]))
+    idx = O.text_select_n_shots(g["labels"], 3)
+    np.testing.assert_array_equal(g["feats"][idx], g["shot_feats"])
+    np.testing.assert_array_equal(g["labels"][idx], g["shot_labels"])
+
+
+@pytest.mark.parametrize("tag", ["lin_zs", "mlp_lt", "lin_imgonly"])
+def test_full_train_run_matches_reference(tag):
+    """Seed-identical replay of finetune.train(): batch index order, per-step
+    losses, eval accuracies, early-stop iteration, best/final weights."""
+    g = load_golden("train_" + tag)
+    (d_img, text_indim, C, B, max_iters, eval_freq, patience, lr, wd, alpha,
+     learnable, zeroshot, seed) = g["cfg"]
+    C, B, max_iters, eval_freq, patience, seed = map(int, (C, B, max_iters, eval_freq, patience, seed))
+    modality = str(g["modality"])
+    st = O.HeadState(g["w_head_init"].copy(), g["w_proj_init"].copy() if "w_proj_init" in g.files else None,
+                     1.0, 1.0, bool(learnable))
+    if zeroshot:
+        st.w_head = O.zero_shot_weights(g["x_txt"], g["y_txt"], C)
+    opt = O.OptState(str(g["optim"]), float(wd))
+    sched = O.LRSchedule(lr, "cosine", 50, max_iters, "linear", 1e-5)
+    # reproduce the global-RNG position the reference had when train() started:
+    # set_random_seed(seed) then the model's nn.Linear inits (finetune.py:452-454, head.py:65,68)
+    torch.manual_seed(seed)
+    d_sh = int(text_indim) if text_indim > 0 else int(d_img)
+    if text_indim > 0:
+        torch.nn.Linear(int(d_img), d_sh, bias=False)
+    torch.nn.Linear(d_sh, C, bias=False)
+    rec = {}
+    out = O.train_loop(st, opt, sched, (g["x_img"], g["y_img"]),
+                       None if modality == "image" else (g["x_txt"], g["y_txt"]),
+                       (g["x_val"], g["y_val"]), (g["x_test"], g["y_test"]),
+                       B, max_iters, float(alpha), eval_freq, patience, record=rec)
+    n = int(g["n_steps"])
+    assert len(rec["loss_img"]) == n
+    np.testing.assert_array_equal(np.concatenate(rec["idx_img"]), g["idx_img"])
+    ce = g["train_ce"]
+    if modality == "image":
+        np.testing.assert_allclose(rec["loss_img"], ce, atol=1e-4)
+    else:
+        np.testing.assert_array_equal(np.concatenate(rec["idx_txt"]), g["idx_txt"])
+        np.testing.assert_allclose(rec["loss_img"], ce[0::2], atol=1e-4)
+        np.testing.assert_allclose(rec["loss_txt"], ce[1::2], atol=1e-4)
+    # reference validates once more after restoring the best weights (finetune.py:275)
+    np.testing.assert_allclose(rec["val_acc"], g["val_acc"][:len(rec["val_acc"])], atol=1e-6)
+    np.testing.assert_allclose(rec["val_loss"], g["val_loss"][:len(rec["val_loss"])], atol=1e-4)
+    assert out["iter"] == int(g["best_iter"])
+    assert abs(out["val_acc"] - float(g["best_val_acc"])) < 1e-6
+    np.testing.assert_allclose(st.w_head, g["w_head_best"], atol=5e-6, rtol=1e-4)
+    if st.w_proj is not None:
+        np.testing.assert_allclose(st.w_proj, g["w_proj_best"], atol=5e-6, rtol=1e-4)
+    tl, ta = O.validate(st, g["x_test"], g["y_test"], B)
+    assert abs(ta - float(g["test_acc"])) < 1e-6 and abs(tl - float(g["test_loss"])) < 1e-4
