@@ -1,0 +1,155 @@
+/*
+ * umlh.h -- C ABI of the MI355X-native UML head fine-tune hot path.
+ *
+ * The reference (OEmiliatanO/Unpaired-Multimodal-Learning) has no FFI / plugin
+ * boundary: the hot path sits behind a Python duck-typed contract between
+ * vision_language/finetune.py:train() and the model / optimizer / scheduler /
+ * loader objects it is handed.  This header is the
+ * boundary a maintainer binds underneath that contract (ctypes stub in
+ * INTEGRATION.md).  Each entry point cites the reference lines it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "device" is HIP device memory
+ *     owned by the caller (torch allocates it); the library never allocates,
+ *     frees or synchronises, so every call is graph-capturable.
+ *   - every function returns 0 on success or a negative UMLH_E_* code;
+ *     umlh_last_error() returns a thread-local message for the last failure.
+ *   - all work is enqueued on the hipStream_t passed as `void* stream`
+ *     (asynchronous w.r.t. the host); a handle is not thread-safe.
+ *   - features are row-major fp32 [rows, dim]; labels are int64 (torch.long);
+ *     optional `index` (int64) gathers rows from a device-resident table, which
+ *     replaces the DataLoader collate of finetune.py:33-39,165-172.
+ */
+#ifndef UMLH_H
+#define UMLH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMLH_OK              0
+#define UMLH_E_INVALID      -1   /* bad argument / unsupported shape            */
+#define UMLH_E_UNBOUND      -2   /* umlh_bind() not called / workspace too small */
+#define UMLH_E_HIP          -3   /* a HIP runtime call failed                   */
+#define UMLH_E_NOGPU        -4   /* no gfx950 device visible                    */
+
+/* engine/optimizer/optim.py:6,15-31 AVAI_OPTIMS */
+#define UMLH_OPT_SGD   0   /* torch.optim.SGD(momentum=0.9, nesterov=False)  optim.py:34-48 */
+#define UMLH_OPT_ADAM  1   /* torch.optim.Adam(betas=(0.9,0.999))            optim.py:50-59 */
+#define UMLH_OPT_ADAMW 2   /* torch.optim.AdamW(betas=(0.9,0.999))           optim.py:61-71 */
+
+#define UMLH_PREC_FP32 0   /* f32-input MFMA (exact fp32 fma chain): the parity mode      */
+#define UMLH_PREC_BF16 1   /* bf16 operands, fp32 accumulate: the throughput mode         */
+
+typedef struct umlh_handle_s* umlh_handle_t;
+
+/* Shape + optimizer of one head.  Mirrors the constructor arguments of
+ * engine/models/head.py:39-70 (UML) / :101-125 (UMLClip) and of
+ * engine/optimizer/optim.py:15 build_optimizer. */
+typedef struct {
+    int32_t d_img;          /* image feature dim (vision_model.num_features)                 */
+    int32_t d_shared;       /* head input dim (text_indim if has_proj else d_img)            */
+    int32_t num_classes;    /* C, 1..1024                                                    */
+    int32_t has_proj;       /* 1: img_proj Linear(d_img -> d_shared, bias=False) head.py:64-66 */
+    int32_t learnable_temp; /* 1: img_scale / txt_scale are parameters        head.py:69-70 */
+    int32_t optimizer;      /* UMLH_OPT_*                                                    */
+    int32_t precision;      /* UMLH_PREC_*                                                   */
+    int32_t max_rows_img;   /* per-step row capacity, image modality                         */
+    int32_t max_rows_txt;   /* per-step row capacity, text modality                          */
+    double  beta1, beta2, eps, momentum, weight_decay;  /* python floats of optim.py:9,12 */
+} umlh_config_t;
+
+/* Caller-owned device state (torch tensors): parameters in reference
+ * parameters() order img_proj.weight, head.weight, img_scale, txt_scale, and the
+ * optimizer state torch.optim keeps for each (exp_avg / momentum_buffer, exp_avg_sq). */
+typedef struct {
+    float* w_head;  float* m_head;  float* v_head;     /* [C, d_shared]                    */
+    float* w_proj;  float* m_proj;  float* v_proj;     /* [d_shared, d_img] or NULL        */
+    float* scales;  float* m_scales; float* v_scales;  /* [2] = {img_scale, txt_scale}     */
+    void*    workspace;                                /* >= umlh_workspace_bytes(cfg)     */
+    uint64_t workspace_bytes;
+} umlh_buffers_t;
+
+/* One modality's rows for one step: what fetch_next() + .to(device) deliver in
+ * finetune.py:164-174, as (table, index) instead of a collated copy. */
+typedef struct {
+    const float*   feats;       /* device [table_rows, dim] fp32                           */
+    const int64_t* labels;      /* device [table_rows]                                     */
+    const int64_t* index;       /* device [rows] row ids into feats/labels, NULL = 0..rows-1 */
+    int32_t        rows;        /* rows processed by THIS rank in this step (0 = absent)   */
+    int32_t        global_rows; /* denominator of the CE mean: rows summed over all ranks  */
+} umlh_batch_t;
+
+/* Per-step scalars: lr = scheduler value used by this optimizer.step()
+ * (engine/optimizer/scheduler.py:58-81), step = 1-based count of optimizer steps
+ * (Adam bias correction), alpha = text loss weight (finetune.py:188). */
+typedef struct {
+    double  lr;
+    int64_t step;
+    float   alpha;      /* weight of the text CE   (args.alpha)      finetune.py:188 */
+    float   img_alpha;  /* weight of the image CE  (img_alpha = 1.0) finetune.py:160 */
+} umlh_hyper_t;
+
+/* Device float[UMLH_N_SCALARS] written by train/grad/eval calls. */
+#define UMLH_S_LOSS_IMG   0   /* mean CE over image rows   finetune.py:186 */
+#define UMLH_S_LOSS_TXT   1   /* mean CE over text rows    finetune.py:187 */
+#define UMLH_S_ACC_IMG    2   /* top-1 accuracy, image     finetune.py:197 */
+#define UMLH_S_ACC_TXT    3   /* top-1 accuracy, text      finetune.py:198 */
+#define UMLH_S_GSCALE_IMG 4   /* d loss / d img_scale                      */
+#define UMLH_S_GSCALE_TXT 5   /* d loss / d txt_scale                      */
+#define UMLH_S_CORRECT    6   /* eval: number of correct rows (as float)   */
+#define UMLH_S_LOSS_SUM   7   /* eval: sum of per-row CE                   */
+#define UMLH_N_SCALARS    8
+
+const char* umlh_last_error(void);
+int  umlh_version(void);
+
+/* Bytes of workspace a handle with this config needs (0 on invalid config). */
+uint64_t umlh_workspace_bytes(const umlh_config_t* cfg);
+
+int  umlh_create(const umlh_config_t* cfg, umlh_handle_t* out);
+int  umlh_destroy(umlh_handle_t h);
+/* Attach parameter / optimizer-state / workspace buffers (state_dict round trips
+ * stay on the torch side: finetune.py:249,274). */
+int  umlh_bind(umlh_handle_t h, const umlh_buffers_t* bufs);
+
+/* head.weight.data = get_zero_shot_weights(...)  head.py:22-37,96-98: per-class
+ * mean of the text rows (rows of classes without text stay 0), rows L2-normalised. */
+int  umlh_zero_shot_init(umlh_handle_t h, const float* text_feats, const int64_t* text_labels,
+                         int64_t n_text, void* stream);
+
+/* model(images, text_features) logits, unfused, for callers that want the
+ * tensors (head.py:77-84 / :131-137).  modality 0 = image path (through img_proj
+ * when has_proj, scaled by img_scale), 1 = text path (txt_scale).
+ * logits_out: device [rows, C] fp32. */
+int  umlh_logits(umlh_handle_t h, const umlh_batch_t* batch, int modality, float* logits_out, void* stream);
+
+/* One whole training step (finetune.py:180-195 minus logging): fused
+ * features x W^T * scale -> softmax-CE -> dZ, dW(+dW_proj, dscale), optimizer
+ * update of every parameter.  Either batch may have rows == 0 (modality absent,
+ * finetune.py:373-380).  scalars_out: device float[UMLH_N_SCALARS] or NULL. */
+int  umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
+                     const umlh_hyper_t* hyper, float* scalars_out, void* stream);
+
+/* Data-parallel split of the step: gradients only, laid out as ONE flat fp32
+ * buffer [g_head | g_proj | g_scales(2) | scalars(UMLH_N_SCALARS)] inside the
+ * workspace, already divided by batch->global_rows so a SUM all-reduce over ranks
+ * yields the single-GPU gradient; then the update from that buffer. */
+int  umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
+                    const umlh_hyper_t* hyper, void* stream);
+int  umlh_grad_buffer(umlh_handle_t h, float** device_ptr, uint64_t* n_floats);
+int  umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hyper, float* scalars_out, void* stream);
+
+/* validate() inner loop for one batch (finetune.py:295-308): logits -> argmax ->
+ * CE, nothing leaves the device.  Writes scalars_out[UMLH_S_CORRECT] (count) and
+ * scalars_out[UMLH_S_LOSS_SUM] (sum of row losses); the caller forms the
+ * per-batch means (finetune.py:311-312). */
+int  umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* batch, float* scalars_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMLH_H */

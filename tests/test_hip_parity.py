@@ -1,0 +1,257 @@
+"""GPU parity: the HIP path (through the C ABI) against the committed golden
+vectors of the reference and against the CPU oracle on seeded inputs.
+
+Tolerances: logits / loss 1e-4 absolute (north_star, fp32); gradients and
+weights relative to their scale (fp32 reduction-order noise)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import uml_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _t(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def _engine(state: O.HeadState, optimizer="adamw", wd=0.0, max_img=64, max_txt=64, **kw):
+    import umlh
+    C, ds = state.w_head.shape
+    di = state.w_proj.shape[1] if state.w_proj is not None else ds
+    e = umlh.HeadEngine(di, ds, C, has_proj=state.w_proj is not None, learnable_temp=state.learnable_temp,
+                        optimizer=optimizer, weight_decay=wd, max_rows_img=max_img, max_rows_txt=max_txt,
+                        device=DEV, **kw)
+    e.w_head.copy_(_t(state.w_head))
+    if state.w_proj is not None:
+        e.w_proj.copy_(_t(state.w_proj))
+    e.scales.copy_(torch.tensor([state.img_scale, state.txt_scale], dtype=torch.float32))
+    return e
+
+
+def _rb(x, y, index=None):
+    import umlh
+    return umlh.RowBatch(_t(x, torch.float32), _t(y, torch.int64), None if index is None else _t(index, torch.int64))
+
+
+def _unpack_grads(e, flat):
+    flat = flat.detach().cpu().numpy()
+    nh = e.num_classes * e.d_shared
+    npj = e.d_shared * e.d_img if e.has_proj else 0
+    gh = flat[:nh].reshape(e.num_classes, e.d_shared)
+    gp = flat[nh:nh + npj].reshape(e.d_shared, e.d_img) if npj else None
+    gs = flat[nh + npj:nh + npj + 2]
+    sc = flat[nh + npj + 2:]
+    return gh, gp, gs, sc
+
+
+STEP_CASES = ["clip_d64_c10", "clip_d512_c100", "clip_d128_c1000", "lin_d96_c37",
+              "mlp_d48_t64_c10", "mlp_d96_t160_c20"]
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_step_against_reference_golden(case):
+    import umlh
+    g = load_golden("step_" + case)
+    learn = "g_img_scale" in g.files
+    st = O.HeadState(g["w_head"].copy(), g["w_proj"].copy() if "w_proj" in g.files else None,
+                     float(g["scale_img"]), float(g["scale_txt"]), learn)
+    e = _engine(st)
+    bi, bt = _rb(g["x_img"], g["y_img"]), _rb(g["x_txt"], g["y_txt"])
+    zi = e.logits(bi, 0).cpu().numpy()
+    zt = e.logits(bt, 1).cpu().numpy()
+    np.testing.assert_allclose(zi, g["img_logits"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(zt, g["txt_logits"], atol=1e-4, rtol=0)
+    flat = e.grad_step(bi, bt, alpha=float(g["alpha"]))
+    torch.cuda.synchronize()
+    gh, gp, gs, sc = _unpack_grads(e, flat)
+    assert abs(sc[umlh.S_LOSS_IMG] - float(g["loss_img"])) < 1e-4
+    assert abs(sc[umlh.S_LOSS_TXT] - float(g["loss_txt"])) < 1e-4
+    assert abs(sc[umlh.S_ACC_IMG] - float(g["acc_img"])) < 1e-6
+    assert abs(sc[umlh.S_ACC_TXT] - float(g["acc_txt"])) < 1e-6
+    s = np.abs(g["g_head"]).max()
+    np.testing.assert_allclose(gh, g["g_head"], atol=3e-5 * s, rtol=1e-4)
+    if gp is not None:
+        np.testing.assert_allclose(gp, g["g_proj"], atol=3e-5 * np.abs(g["g_proj"]).max(), rtol=1e-4)
+    if learn:
+        assert abs(gs[0] - float(g["g_img_scale"])) < 2e-5
+        assert abs(gs[1] - float(g["g_txt_scale"])) < 2e-5
+
+
+@pytest.mark.parametrize("tag,optim", [("adamw_lin", "adamw"), ("sgd_lin", "sgd"), ("adam_lin", "adam"),
+                                       ("adamw_mlp", "adamw")])
+def test_trajectory_against_reference_golden(tag, optim):
+    import umlh
+    g = load_golden("traj_" + tag)
+    lr, wd, warm, max_iter, wlr, alpha = g["hyper"]
+    learn = tag.endswith("mlp")
+    st = O.HeadState(g["w_head0"].copy(), g["w_proj0"].copy() if "w_proj0" in g.files else None, 1.0, 1.0, learn)
+    e = _engine(st, optimizer=optim, wd=float(wd))
+    steps = g["x_img"].shape[0]
+    scal = torch.zeros(steps, umlh.N_SCALARS, device=DEV)
+    for k in range(steps):
+        e.train_step(_rb(g["x_img"][k], g["y_img"][k]), _rb(g["x_txt"][k], g["y_txt"][k]),
+                     lr=float(g["lr"][k]), step=k + 1, alpha=float(alpha), scalars_out=scal[k])
+        key = f"w_head_after_{k}"
+        if key in g.files:
+            np.testing.assert_allclose(e.w_head.cpu().numpy(), g[key], atol=3e-6, rtol=3e-5, err_msg=key)
+            if e.has_proj:
+                np.testing.assert_allclose(e.w_proj.cpu().numpy(), g[f"w_proj_after_{k}"], atol=3e-6, rtol=3e-5)
+    sc = scal.cpu().numpy()
+    np.testing.assert_allclose(sc[:, umlh.S_LOSS_IMG], g["loss_img"], atol=1e-4)
+    np.testing.assert_allclose(sc[:, umlh.S_LOSS_TXT], g["loss_txt"], atol=1e-4)
+    np.testing.assert_allclose(e.m_head.cpu().numpy(), g["m_head_final"], atol=2e-7, rtol=2e-3)
+    if "v_head_final" in g.files:
+        np.testing.assert_allclose(e.v_head.cpu().numpy(), g["v_head_final"], atol=1e-10, rtol=2e-3)
+    if learn:
+        s = e.scales.cpu().numpy()
+        assert abs(s[0] - float(g["img_scale_final"])) < 2e-5 and abs(s[1] - float(g["txt_scale_final"])) < 2e-5
+
+
+def test_zero_shot_init_golden():
+    g = load_golden("text_side")
+    C = int(g["num_classes"])
+    st = O.HeadState(np.zeros((C, g["feats"].shape[1]), np.float32))
+    e = _engine(st)
+    e.zero_shot_init(torch.as_tensor(g["feats"]), torch.as_tensor(g["labels"]))
+    w = e.w_head.cpu().numpy()
+    np.testing.assert_allclose(w, g["zero_shot_w"], atol=1e-6)
+    assert np.all(w[1] == 0) and np.all(w[7] == 0)
+
+
+def _random_case(rng, di, ds, C, n_img, n_txt, bi, bt, proj, learn, scale):
+    xi = rng.standard_normal((n_img, di)).astype(np.float32)
+    xi /= np.linalg.norm(xi, axis=1, keepdims=True)
+    xt = rng.standard_normal((n_txt, ds)).astype(np.float32)
+    xt /= np.linalg.norm(xt, axis=1, keepdims=True)
+    yi = rng.integers(0, C, n_img)
+    yt = rng.integers(0, C, n_txt)
+    w = rng.standard_normal((C, ds)).astype(np.float32)
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    wp = (rng.standard_normal((ds, di)) / np.sqrt(di)).astype(np.float32) if proj else None
+    ii = rng.permutation(n_img)[:bi] if bi else None
+    ti = rng.permutation(n_txt)[:bt] if bt else None
+    st = O.HeadState(w, wp, scale, scale * 0.5 if learn else scale, learn)
+    return st, xi, yi, xt, yt, ii, ti
+
+
+@pytest.mark.parametrize("di,ds,C,bi,bt,proj,learn,scale", [
+    (96, 96, 37, 50, 33, False, False, 100.0),      # ragged rows, C not a tile multiple
+    (64, 64, 10, 300, 7, False, False, 30.0),       # several sample tiles / one tiny segment
+    (40, 56, 12, 21, 40, True, True, 1.3),          # img_proj + learnable temperature
+    (128, 128, 397, 64, 64, False, False, 100.0),   # CTW=2 path (SUN397)
+    (70, 70, 200, 45, 0, False, False, 20.0),       # image-only modality (finetune.py:373-376)
+    (32, 48, 1000, 33, 65, True, False, 1.0),       # C=1000 with projection
+    (30, 30, 101, 17, 19, False, True, 2.0),        # d not a multiple of 4 -> scalar load path
+])
+def test_gathered_step_against_oracle(di, ds, C, bi, bt, proj, learn, scale):
+    import umlh
+    rng = np.random.default_rng(di * 1000 + C)
+    st, xi, yi, xt, yt, ii, ti = _random_case(rng, di, ds, C, 400, 350, bi, bt, proj, learn, scale)
+    e = _engine(st, max_img=512, max_txt=128)
+    b_img = _rb(xi, yi, ii) if bi else None
+    b_txt = _rb(xt, yt, ti) if bt else None
+    flat = e.grad_step(b_img, b_txt, alpha=0.7)
+    torch.cuda.synchronize()
+    gh, gp, gs, sc = _unpack_grads(e, flat)
+    so = O.step_grads(st, xi[ii] if bi else None, yi[ii] if bi else None,
+                      xt[ti] if bt else None, yt[ti] if bt else None, 0.7)
+    if bi:
+        np.testing.assert_allclose(e.logits(b_img, 0).cpu().numpy(), so.zi, atol=1e-4, rtol=0)
+        assert abs(sc[umlh.S_LOSS_IMG] - so.loss_img) < 1e-4 and abs(sc[umlh.S_ACC_IMG] - so.acc_img) < 1e-6
+    if bt:
+        np.testing.assert_allclose(e.logits(b_txt, 1).cpu().numpy(), so.zt, atol=1e-4, rtol=0)
+        assert abs(sc[umlh.S_LOSS_TXT] - so.loss_txt) < 1e-4 and abs(sc[umlh.S_ACC_TXT] - so.acc_txt) < 1e-6
+    s = np.abs(so.grads["w_head"]).max()
+    np.testing.assert_allclose(gh, so.grads["w_head"], atol=3e-5 * s, rtol=2e-4)
+    if proj and bi:
+        np.testing.assert_allclose(gp, so.grads["w_proj"], atol=3e-5 * np.abs(so.grads["w_proj"]).max(), rtol=2e-4)
+    if learn:
+        if bi:
+            assert abs(gs[0] - float(so.grads["img_scale"])) < 3e-5
+        if bt:
+            assert abs(gs[1] - float(so.grads["txt_scale"])) < 3e-5
+
+
+def test_eval_batch_matches_validate():
+    import umlh
+    rng = np.random.default_rng(5)
+    st, xi, yi, *_ = _random_case(rng, 64, 64, 100, 300, 10, 0, 0, False, False, 100.0)
+    e = _engine(st, max_img=128)
+    losses, correct = [], 0
+    sc = torch.zeros(3, umlh.N_SCALARS, device=DEV)
+    for j, s in enumerate(range(0, 300, 128)):
+        e.eval_batch(_rb(xi[s:s + 128], yi[s:s + 128]), sc[j])
+    sc = sc.cpu().numpy()
+    rows = [128, 128, 44]
+    val_loss = np.mean([sc[j, umlh.S_LOSS_SUM] / rows[j] for j in range(3)])
+    val_acc = sc[:, umlh.S_CORRECT].sum() / 300
+    ol, oa = O.validate(st, xi, yi, 128, rng_draw=False)
+    assert abs(val_loss - ol) < 1e-4 and abs(val_acc - oa) < 1e-6
+
+
+def test_split_grad_then_update_equals_fused_step():
+    """umlh_grad_step + umlh_apply_update (the data-parallel split) == umlh_train_step."""
+    rng = np.random.default_rng(9)
+    st, xi, yi, xt, yt, ii, ti = _random_case(rng, 48, 64, 50, 200, 200, 96, 80, True, True, 3.0)
+    e1 = _engine(st, wd=0.01, max_img=128, max_txt=128)
+    e2 = _engine(st, wd=0.01, max_img=128, max_txt=128)
+    for k in range(3):
+        e1.train_step(_rb(xi, yi, ii), _rb(xt, yt, ti), lr=1e-3, step=k + 1, alpha=0.5)
+        e2.grad_step(_rb(xi, yi, ii), _rb(xt, yt, ti), alpha=0.5)
+        e2.apply_update(lr=1e-3, step=k + 1)
+    torch.cuda.synchronize()
+    for a, b in [(e1.w_head, e2.w_head), (e1.w_proj, e2.w_proj), (e1.scales, e2.scales), (e1.m_head, e2.m_head)]:
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-7, rtol=1e-6)
+
+
+def test_full_size_cfg2_step_against_oracle():
+    """BASELINE config 2 shape: d=512, C=1000, 4096 image + 4096 text rows gathered from
+    larger tables, AdamW; two steps vs the oracle, plus the CE-gradient property
+    sum_c dW[c,:] = 0."""
+    import umlh
+    rng = np.random.default_rng(0)
+    d, C, B = 512, 1000, 4096
+    st, xi, yi, xt, yt, ii, ti = _random_case(rng, d, d, C, 3 * B, 2 * B, B, B, False, False, 100.0)
+    e = _engine(st, optimizer="adamw", wd=0.01, max_img=B, max_txt=B)
+    flat = e.grad_step(_rb(xi, yi, ii), _rb(xt, yt, ti), alpha=1.0)
+    torch.cuda.synchronize()
+    gh, _, _, sc = _unpack_grads(e, flat)
+    so = O.step_grads(st, xi[ii], yi[ii], xt[ti], yt[ti], 1.0)
+    assert abs(sc[umlh.S_LOSS_IMG] - so.loss_img) < 1e-4 and abs(sc[umlh.S_LOSS_TXT] - so.loss_txt) < 1e-4
+    s = np.abs(so.grads["w_head"]).max()
+    np.testing.assert_allclose(gh, so.grads["w_head"], atol=5e-5 * s, rtol=5e-4)
+    assert np.abs(gh.sum(axis=0)).max() < 1e-4 * np.abs(gh).sum(axis=0).max()
+    opt = O.OptState("adamw", 0.01)
+    for k in range(2):
+        so = O.step_grads(st, xi[ii], yi[ii], xt[ti], yt[ti], 1.0)
+        O.optimizer_step(st, so.grads, opt, 1e-3)
+        e.train_step(_rb(xi, yi, ii), _rb(xt, yt, ti), lr=1e-3, step=k + 1, alpha=1.0)
+    # Adam's first steps move every weight by ~lr*sign(g): the handful of elements whose
+    # gradient is at fp32-noise level (|g| ~ eps) may legitimately take the other sign.
+    diff = np.abs(e.w_head.cpu().numpy() - st.w_head)
+    assert (diff > 2e-5 + 1e-4 * np.abs(st.w_head)).mean() < 1e-4
+    assert diff.max() <= 2 * 2 * 1e-3 + 1e-6
+
+
+def test_argument_errors_are_loud():
+    import umlh
+    with pytest.raises(AssertionError):
+        umlh.HeadEngine(8, 8, 4, optimizer="lion", device=DEV)
+    with pytest.raises(umlh.UmlhError):
+        umlh.HeadEngine(8, 8, 5000, device=DEV)                 # C > 1024 unsupported
+    st = O.HeadState(np.zeros((4, 8), np.float32))
+    e = _engine(st, max_img=16, max_txt=16)
+    x = np.zeros((32, 8), np.float32)
+    y = np.zeros(32, np.int64)
+    with pytest.raises(umlh.UmlhError):
+        e.train_step(_rb(x, y), None, lr=1e-3, step=1)          # rows > capacity
+    with pytest.raises(umlh.UmlhError):
+        e.train_step(None, None, lr=1e-3, step=1)               # finetune.py:123

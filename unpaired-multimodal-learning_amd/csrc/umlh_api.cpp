@@ -1,0 +1,442 @@
+// Host side of the C ABI declared in include/umlh.h: argument checks, workspace
+// partitioning, per-step launch sequences.  No allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "umlh_common.h"
+
+extern "C" {
+int umlh_f32_fwd_config(int C, int* ctw, int* wc);
+int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t stream);
+int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream);
+int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long long slab_stride, long long n,
+                              float* grad_out, float* p, float* m, float* v, const OptArgs* o, hipStream_t stream);
+int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream);
+int umlh_launch_zero_shot(const float* feats, const int64_t* labels, long long n, int d, int C, float* w,
+                          hipStream_t stream);
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
+
+struct Layout {                 // workspace partition, in floats from the base
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, total;
+    int rcap_img, rcap_txt, ldz;     // padded row capacities
+    int scap_head, scap_proj;        // split-K slab capacities
+    long long n_head, n_proj;        // parameter counts
+    int max_blocks;
+};
+
+static int split_cap(int M, int N) {
+    long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    long long want = 256 / tiles;
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    return (int)want;
+}
+
+static bool make_layout(const umlh_config_t& c, Layout& L) {
+    if (c.d_img < 1 || c.d_shared < 1 || c.num_classes < 1 || c.num_classes > 1024) return false;
+    if (!c.has_proj && c.d_img != c.d_shared) return false;
+    if (c.max_rows_img < 0 || c.max_rows_txt < 0 || c.max_rows_img + c.max_rows_txt < 1) return false;
+    if (c.optimizer < UMLH_OPT_SGD || c.optimizer > UMLH_OPT_ADAMW) return false;
+    if (c.precision != UMLH_PREC_FP32) return false;
+    L.rcap_img = (int)round_up(c.max_rows_img, 256);
+    L.rcap_txt = (int)round_up(c.max_rows_txt, 256);
+    L.ldz = L.rcap_img + L.rcap_txt;
+    L.n_head = (long long)c.num_classes * c.d_shared;
+    L.n_proj = c.has_proj ? (long long)c.d_shared * c.d_img : 0;
+    L.scap_head = split_cap(c.num_classes, c.d_shared);
+    L.scap_proj = c.has_proj ? split_cap(c.d_shared, c.d_img) : 0;
+    L.max_blocks = L.ldz / 32 + 2;
+    long long off = 0;
+    auto take = [&](long long n) { long long o = off; off += round_up(n, 64); return o; };
+    L.dzt = take((long long)c.num_classes * L.ldz);
+    L.h = take(c.has_proj ? (long long)L.rcap_img * c.d_shared : 0);
+    L.dht = take(c.has_proj ? (long long)c.d_shared * L.rcap_img : 0);
+    L.slabs_head = take((long long)L.scap_head * L.n_head);
+    L.slabs_proj = take((long long)L.scap_proj * L.n_proj);
+    L.partials = take((long long)L.max_blocks * 4);
+    L.grads = take(L.n_head + L.n_proj + 2 + UMLH_N_SCALARS);
+    L.total = off;
+    return true;
+}
+
+struct umlh_handle_s {
+    umlh_config_t cfg;
+    umlh_buffers_t buf;
+    Layout L;
+    bool bound;
+    int ctw, wc, ts;            // fwd_ce tile configuration
+    // state carried from umlh_grad_step to umlh_apply_update
+    int last_rows_img, last_rows_txt;
+};
+
+const char* umlh_last_error(void) { return g_err; }
+int umlh_version(void) { return 1; }
+
+uint64_t umlh_workspace_bytes(const umlh_config_t* cfg) {
+    Layout L;
+    if (!cfg || !make_layout(*cfg, L)) return 0;
+    return (uint64_t)L.total * sizeof(float);
+}
+
+int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
+    if (!cfg || !out) return fail(UMLH_E_INVALID, "umlh_create: null argument");
+    Layout L;
+    if (!make_layout(*cfg, L))
+        return fail(UMLH_E_INVALID,
+                    "umlh_create: unsupported config (d_img=%d d_shared=%d C=%d has_proj=%d opt=%d prec=%d rows=%d/%d)",
+                    cfg->d_img, cfg->d_shared, cfg->num_classes, cfg->has_proj, cfg->optimizer, cfg->precision,
+                    cfg->max_rows_img, cfg->max_rows_txt);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(UMLH_E_NOGPU, "umlh_create: no HIP device visible");
+    umlh_handle_s* h = new (std::nothrow) umlh_handle_s();
+    if (!h) return fail(UMLH_E_INVALID, "umlh_create: out of host memory");
+    h->cfg = *cfg;
+    h->L = L;
+    h->bound = false;
+    h->ts = umlh_f32_fwd_config(cfg->num_classes, &h->ctw, &h->wc);
+    h->last_rows_img = h->last_rows_txt = 0;
+    memset(&h->buf, 0, sizeof(h->buf));
+    *out = h;
+    return UMLH_OK;
+}
+
+int umlh_destroy(umlh_handle_t h) {
+    delete h;
+    return UMLH_OK;
+}
+
+int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
+    if (!h || !b) return fail(UMLH_E_INVALID, "umlh_bind: null argument");
+    if (!b->w_head || !b->m_head || !b->workspace) return fail(UMLH_E_INVALID, "umlh_bind: w_head/m_head/workspace required");
+    if (h->cfg.optimizer != UMLH_OPT_SGD && !b->v_head) return fail(UMLH_E_INVALID, "umlh_bind: v_head required for adam/adamw");
+    if (h->cfg.has_proj && (!b->w_proj || !b->m_proj || (h->cfg.optimizer != UMLH_OPT_SGD && !b->v_proj)))
+        return fail(UMLH_E_INVALID, "umlh_bind: img_proj buffers required when has_proj");
+    if (!b->scales) return fail(UMLH_E_INVALID, "umlh_bind: scales[2] required");
+    if (h->cfg.learnable_temp && (!b->m_scales || !b->v_scales))
+        return fail(UMLH_E_INVALID, "umlh_bind: m_scales/v_scales required when learnable_temp");
+    if (b->workspace_bytes < (uint64_t)h->L.total * sizeof(float))
+        return fail(UMLH_E_UNBOUND, "umlh_bind: workspace too small (%llu < %llu bytes)",
+                    (unsigned long long)b->workspace_bytes, (unsigned long long)h->L.total * sizeof(float));
+    if ((reinterpret_cast<uintptr_t>(b->workspace) & 255) != 0) return fail(UMLH_E_INVALID, "umlh_bind: workspace must be 256-B aligned");
+    h->buf = *b;
+    h->bound = true;
+    return UMLH_OK;
+}
+
+static inline float* ws(umlh_handle_t h, long long off) { return static_cast<float*>(h->buf.workspace) + off; }
+
+static int check_batch(umlh_handle_t h, const umlh_batch_t* b, int cap, const char* who) {
+    if (!b) return UMLH_OK;
+    if (b->rows < 0 || b->rows > cap) return fail(UMLH_E_INVALID, "%s: rows=%d outside [0,%d]", who, b->rows, cap);
+    if (b->rows > 0 && (!b->feats || !b->labels)) return fail(UMLH_E_INVALID, "%s: feats/labels null", who);
+    if (b->rows > 0 && b->global_rows < b->rows) return fail(UMLH_E_INVALID, "%s: global_rows=%d < rows=%d", who, b->global_rows, b->rows);
+    return UMLH_OK;
+}
+
+static OptArgs make_opt(const umlh_config_t& c, const umlh_hyper_t& hy) {
+    OptArgs o;
+    memset(&o, 0, sizeof(o));
+    o.kind = c.optimizer;
+    o.lr = (float)hy.lr;
+    o.decay = (float)(1.0 - hy.lr * c.weight_decay);
+    double t = (double)(hy.step < 1 ? 1 : hy.step);
+    double bc1 = 1.0 - std::pow(c.beta1, t);
+    double bc2 = 1.0 - std::pow(c.beta2, t);
+    o.neg_step_size = (float)(-(hy.lr / bc1));
+    o.bc2_sqrt = (float)std::sqrt(bc2);
+    o.beta1 = (float)c.beta1;
+    o.one_m_beta1 = (float)(1.0 - c.beta1);
+    o.beta2 = (float)c.beta2;
+    o.one_m_beta2 = (float)(1.0 - c.beta2);
+    o.eps = (float)c.eps;
+    o.momentum = (float)c.momentum;
+    o.wd = (float)c.weight_decay;
+    return o;
+}
+
+#define HIPCHK(expr, what)                                                                  \
+    do {                                                                                    \
+        int _e = (expr);                                                                    \
+        if (_e != 0) return fail(UMLH_E_HIP, "%s: HIP error %d (%s)", what, _e, hipGetErrorString((hipError_t)_e)); \
+    } while (0)
+
+int umlh_zero_shot_init(umlh_handle_t h, const float* text_feats, const int64_t* text_labels, int64_t n_text,
+                        void* stream) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_zero_shot_init: handle not bound");
+    if (!text_feats || !text_labels || n_text < 0) return fail(UMLH_E_INVALID, "umlh_zero_shot_init: bad arguments");
+    HIPCHK(umlh_launch_zero_shot(text_feats, text_labels, n_text, h->cfg.d_shared, h->cfg.num_classes,
+                                 h->buf.w_head, (hipStream_t)stream), "zero_shot");
+    return UMLH_OK;
+}
+
+// H = X_img[index] W_proj^T into the workspace (head.py:79)
+static int launch_proj_forward(umlh_handle_t h, const umlh_batch_t* img, float* H, hipStream_t st) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = img->feats; g.a_rows = img->index; g.lda = h->cfg.d_img;
+    g.B = h->buf.w_proj; g.ldb = h->cfg.d_img;
+    g.out = H; g.ldo = h->cfg.d_shared;
+    g.M = img->rows; g.N = h->cfg.d_shared; g.K = h->cfg.d_img;
+    g.k_chunk = g.K; g.slab_stride = 0; g.alpha = 1.f;
+    g.k_switch = INT_MAX; g.k_valid1 = g.K; g.k_valid2 = 0;
+    return umlh_f32_launch_gemm(&g, 0, 0, 1, st);
+}
+
+int umlh_logits(umlh_handle_t h, const umlh_batch_t* b, int modality, float* out, void* stream) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_logits: handle not bound");
+    if (!b || !out || (modality != 0 && modality != 1)) return fail(UMLH_E_INVALID, "umlh_logits: bad arguments");
+    int rc = check_batch(h, b, modality == 0 ? h->L.rcap_img : h->L.rcap_txt, "umlh_logits");
+    if (rc) return rc;
+    if (b->rows == 0) return UMLH_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float* F = b->feats;
+    const int64_t* idx = b->index;
+    int ld = h->cfg.d_shared;
+    if (modality == 0 && h->cfg.has_proj) {
+        HIPCHK(launch_proj_forward(h, b, ws(h, h->L.h), st), "proj forward");
+        F = ws(h, h->L.h);
+        idx = nullptr;
+    }
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = F; g.a_rows = idx; g.lda = ld;
+    g.B = h->buf.w_head; g.ldb = h->cfg.d_shared;
+    g.out = out; g.ldo = h->cfg.num_classes;
+    g.M = b->rows; g.N = h->cfg.num_classes; g.K = h->cfg.d_shared;
+    g.k_chunk = g.K; g.alpha = 1.f;
+    g.k_switch = INT_MAX; g.k_valid1 = g.K;
+    g.alpha_ptr = h->buf.scales + modality;             // device-resident logit scale
+    HIPCHK(umlh_f32_launch_gemm(&g, 0, 0, 1, st), "logits gemm");
+    return UMLH_OK;
+}
+
+// Everything of a step up to (not including) the parameter update.
+static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
+                            const umlh_hyper_t* hy, bool want_grad, hipStream_t st, int* n_slabs_head,
+                            int* n_slabs_proj) {
+    const umlh_config_t& c = h->cfg;
+    const Layout& L = h->L;
+    const int ri = img ? img->rows : 0, rt = txt ? txt->rows : 0;
+    const int TS = h->ts;
+    const int nb0 = (ri + TS - 1) / TS, nb1 = (rt + TS - 1) / TS;
+    const int r0p = nb0 * TS, r1p = nb1 * TS;
+    float* H = ws(h, L.h);
+    float* dzt = ws(h, L.dzt);
+
+    if (ri > 0 && c.has_proj) HIPCHK(launch_proj_forward(h, img, H, st), "proj forward");
+
+    FwdArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    SegDesc& s0 = fa.seg[0];
+    SegDesc& s1 = fa.seg[1];
+    if (ri > 0) {
+        s0.feats = c.has_proj ? H : img->feats;
+        s0.feat_index = c.has_proj ? nullptr : img->index;
+        s0.labels = img->labels; s0.label_index = img->index;
+        s0.ld = c.d_shared; s0.rows = ri;
+        s0.w_over_rows = hy->img_alpha / (float)img->global_rows;
+    }
+    s0.scale_ptr = h->buf.scales; s0.col0 = 0; s0.blk0 = 0;
+    if (rt > 0) {
+        s1.feats = txt->feats; s1.feat_index = txt->index;
+        s1.labels = txt->labels; s1.label_index = txt->index;
+        s1.ld = c.d_shared; s1.rows = rt;
+        s1.w_over_rows = hy->alpha / (float)txt->global_rows;
+    }
+    s1.scale_ptr = h->buf.scales + 1; s1.col0 = r0p; s1.blk0 = nb0;
+    fa.W = h->buf.w_head; fa.C = c.num_classes; fa.K = c.d_shared;
+    fa.dzt = want_grad ? dzt : nullptr; fa.ldz = L.ldz;
+    fa.partials = ws(h, L.partials);
+    HIPCHK(umlh_f32_launch_fwd(&fa, h->ctw, h->wc, nb0 + nb1, st), "fwd_ce");
+    if (!want_grad) return UMLH_OK;
+
+    // dW_head[c][k] = sum_r dZ^T[c][r] F[r][k]  over image rows then text rows
+    const int rcols = r0p + r1p;
+    {
+        int want = L.scap_head;
+        int chunk = (int)round_up((rcols + want - 1) / want, KT);
+        if (chunk < 64) chunk = 64;
+        int splits = (rcols + chunk - 1) / chunk;
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = dzt; g.lda = L.ldz;
+        g.M = c.num_classes; g.N = c.d_shared; g.K = rcols;
+        g.B = c.has_proj ? H : (img ? img->feats : nullptr);
+        g.k_rows = c.has_proj ? nullptr : (img ? img->index : nullptr);
+        g.ldb = c.d_shared;
+        g.B2 = txt ? txt->feats : nullptr; g.k_rows2 = txt ? txt->index : nullptr; g.ldb2 = c.d_shared;
+        g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt;
+        g.out = ws(h, L.slabs_head); g.ldo = c.d_shared;
+        g.k_chunk = chunk; g.slab_stride = L.n_head; g.alpha = 1.f;
+        HIPCHK(umlh_f32_launch_gemm(&g, 0, 1, splits, st), "dW_head gemm");
+        *n_slabs_head = splits;
+    }
+    *n_slabs_proj = 0;
+    if (c.has_proj && ri > 0) {
+        // dH^T[n][r] = sum_c W_head[c][n] dZ^T[c][r]   (image columns only)
+        float* dht = ws(h, L.dht);
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = h->buf.w_head; g.lda = c.d_shared;            // A(m=n, k=c) = W[c][n]  (k-major)
+        g.B = dzt; g.ldb = L.ldz;                           // B(n=r, k=c) = dZ^T[c][r]
+        g.M = c.d_shared; g.N = ri; g.K = c.num_classes;
+        g.out = dht; g.ldo = L.rcap_img;
+        g.k_chunk = g.K; g.alpha = 1.f;
+        g.k_switch = INT_MAX; g.k_valid1 = g.K;
+        HIPCHK(umlh_f32_launch_gemm(&g, 1, 1, 1, st), "dH gemm");
+        // dW_proj[n][k] = sum_r dH^T[n][r] X_img[index[r]][k]
+        int want = L.scap_proj;
+        int chunk = (int)round_up((ri + want - 1) / want, KT);
+        if (chunk < 64) chunk = 64;
+        int splits = (ri + chunk - 1) / chunk;
+        GemmArgs p;
+        memset(&p, 0, sizeof(p));
+        p.A = dht; p.lda = L.rcap_img;
+        p.B = img->feats; p.k_rows = img->index; p.ldb = c.d_img;
+        p.M = c.d_shared; p.N = c.d_img; p.K = ri;
+        p.out = ws(h, L.slabs_proj); p.ldo = c.d_img;
+        p.k_chunk = chunk; p.slab_stride = L.n_proj; p.alpha = 1.f;
+        p.k_switch = INT_MAX; p.k_valid1 = ri;
+        HIPCHK(umlh_f32_launch_gemm(&p, 0, 1, splits, st), "dW_proj gemm");
+        *n_slabs_proj = splits;
+    }
+    return UMLH_OK;
+}
+
+static FinalizeArgs make_finalize(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
+                                  const umlh_hyper_t* hy, bool from_partials, float* scalars_out, bool update) {
+    const int ri = img ? img->rows : h->last_rows_img, rt = txt ? txt->rows : h->last_rows_txt;
+    FinalizeArgs f;
+    memset(&f, 0, sizeof(f));
+    f.partials = from_partials ? ws(h, h->L.partials) : nullptr;
+    f.nb0 = (ri + h->ts - 1) / h->ts;
+    f.nb1 = (rt + h->ts - 1) / h->ts;
+    f.inv_rows0 = (img && img->rows > 0) ? 1.f / (float)img->global_rows : 0.f;
+    f.inv_rows1 = (txt && txt->rows > 0) ? 1.f / (float)txt->global_rows : 0.f;
+    f.w0 = hy ? hy->img_alpha : 1.f;
+    f.w1 = hy ? hy->alpha : 1.f;
+    f.tail = ws(h, h->L.grads) + h->L.n_head + h->L.n_proj;
+    f.scalars_out = scalars_out;
+    f.scales = h->buf.scales; f.m_scales = h->buf.m_scales; f.v_scales = h->buf.v_scales;
+    f.update_mask = 0;
+    if (update && h->cfg.learnable_temp) f.update_mask = (ri > 0 ? 1 : 0) | (rt > 0 ? 2 : 0);
+    if (hy) f.opt = make_opt(h->cfg, *hy);
+    return f;
+}
+
+static int check_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
+                      const char* who) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "%s: handle not bound", who);
+    if (!hy) return fail(UMLH_E_INVALID, "%s: hyper is null", who);
+    int rc = check_batch(h, img, h->cfg.max_rows_img, who);
+    if (rc) return rc;
+    rc = check_batch(h, txt, h->cfg.max_rows_txt, who);
+    if (rc) return rc;
+    // finetune.py:123 "At least one of the loaders should be provided"
+    if ((img ? img->rows : 0) + (txt ? txt->rows : 0) == 0) return fail(UMLH_E_INVALID, "%s: both modalities empty", who);
+    return UMLH_OK;
+}
+
+int umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
+                    float* scalars_out, void* stream) {
+    int rc = check_step(h, img, txt, hy, "umlh_train_step");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int sh = 0, sp = 0;
+    rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
+    if (rc) return rc;
+    OptArgs o = make_opt(h->cfg, *hy);
+    FinalizeArgs f = make_finalize(h, img, txt, hy, true, scalars_out, true);
+    HIPCHK(umlh_launch_finalize(&f, st), "finalize");
+    HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, nullptr,
+                                     h->buf.w_head, h->buf.m_head, h->buf.v_head, &o, st), "update head");
+    if (sp > 0)
+        HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj, nullptr,
+                                         h->buf.w_proj, h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
+    return UMLH_OK;
+}
+
+int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
+                   void* stream) {
+    int rc = check_step(h, img, txt, hy, "umlh_grad_step");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int sh = 0, sp = 0;
+    rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
+    if (rc) return rc;
+    OptArgs o = make_opt(h->cfg, *hy);
+    FinalizeArgs f = make_finalize(h, img, txt, hy, true, nullptr, false);
+    HIPCHK(umlh_launch_finalize(&f, st), "finalize");
+    float* grads = ws(h, h->L.grads);
+    HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, grads, nullptr,
+                                     nullptr, nullptr, &o, st), "reduce head");
+    if (h->cfg.has_proj) {
+        if (sp > 0)
+            HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj,
+                                             grads + h->L.n_head, nullptr, nullptr, nullptr, &o, st), "reduce proj");
+        else
+            HIPCHK((int)hipMemsetAsync(grads + h->L.n_head, 0, sizeof(float) * h->L.n_proj, st), "zero proj grad");
+    }
+    h->last_rows_img = img ? img->rows : 0;
+    h->last_rows_txt = txt ? txt->rows : 0;
+    return UMLH_OK;
+}
+
+int umlh_grad_buffer(umlh_handle_t h, float** device_ptr, uint64_t* n_floats) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_grad_buffer: handle not bound");
+    if (device_ptr) *device_ptr = ws(h, h->L.grads);
+    if (n_floats) *n_floats = (uint64_t)(h->L.n_head + h->L.n_proj + 2 + UMLH_N_SCALARS);
+    return UMLH_OK;
+}
+
+int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_out, void* stream) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_apply_update: handle not bound");
+    if (!hy) return fail(UMLH_E_INVALID, "umlh_apply_update: hyper is null");
+    hipStream_t st = (hipStream_t)stream;
+    OptArgs o = make_opt(h->cfg, *hy);
+    float* grads = ws(h, h->L.grads);
+    HIPCHK(umlh_launch_reduce_update(1, grads, 1, h->L.n_head, h->L.n_head, nullptr, h->buf.w_head, h->buf.m_head,
+                                     h->buf.v_head, &o, st), "update head");
+    if (h->cfg.has_proj && h->last_rows_img > 0)
+        HIPCHK(umlh_launch_reduce_update(1, grads + h->L.n_head, 1, h->L.n_proj, h->L.n_proj, nullptr, h->buf.w_proj,
+                                         h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
+    FinalizeArgs f = make_finalize(h, nullptr, nullptr, hy, false, scalars_out, true);
+    HIPCHK(umlh_launch_finalize(&f, st), "finalize");
+    return UMLH_OK;
+}
+
+int umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* b, float* scalars_out, void* stream) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_eval_batch: handle not bound");
+    if (!b || !scalars_out) return fail(UMLH_E_INVALID, "umlh_eval_batch: null argument");
+    int rc = check_batch(h, b, h->cfg.max_rows_img, "umlh_eval_batch");
+    if (rc) return rc;
+    if (b->rows == 0) return fail(UMLH_E_INVALID, "umlh_eval_batch: empty batch");
+    hipStream_t st = (hipStream_t)stream;
+    umlh_hyper_t hy;
+    memset(&hy, 0, sizeof(hy));
+    hy.lr = 0; hy.step = 1; hy.alpha = 1.f; hy.img_alpha = 1.f;
+    int sh = 0, sp = 0;
+    rc = forward_backward(h, b, nullptr, &hy, false, st, &sh, &sp);
+    if (rc) return rc;
+    FinalizeArgs f = make_finalize(h, b, nullptr, &hy, true, scalars_out, false);
+    HIPCHK(umlh_launch_finalize(&f, st), "finalize");
+    return UMLH_OK;
+}

@@ -1,0 +1,95 @@
+// Shared device/host definitions for the UML head kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "umlh.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// K elements staged per LDS chunk in the fp32 kernels (8 MFMA k-steps of 2).
+constexpr int KT = 16;
+
+// Row of a 32x32 MFMA accumulator register: C/D layout is
+// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ---- one modality's rows as the forward kernel sees them ----
+struct SegDesc {
+    const float*   feats;        // [*, ld] fp32
+    const int64_t* feat_index;   // row gather for feats (NULL = identity)
+    const int64_t* labels;       // [*] int64
+    const int64_t* label_index;  // row gather for labels (NULL = identity)
+    const float*   scale_ptr;    // device scalar: logit scale of this modality
+    int   rows;                  // valid rows in this step
+    int   ld;                    // leading dim of feats
+    int   col0;                  // first column of this segment in dZ^T
+    int   blk0;                  // first block of this segment in the grid
+    float w_over_rows;           // loss weight / global row count
+};
+
+struct FwdArgs {
+    SegDesc seg[2];
+    const float* W;              // [C, K] head weight
+    int   C, K;
+    float* dzt;                  // [C, ldz] dZ^T (class-major), NULL = eval (no gradient)
+    int   ldz;
+    float* partials;             // [grid][4] = {loss_sum, correct, gscale_sum, 0}
+};
+
+// ---- generic fp32 GEMM: out[m][n] = alpha * sum_k A(m,k) * B(n,k) ----
+struct GemmArgs {
+    const float* A;  const float* B;  float* out;
+    const int64_t* a_rows;       // TA==0: gather of A rows by m (NULL = identity)
+    const int64_t* k_rows;       // TB==1: gather of B rows by k (NULL = identity)
+    int   M, N, K;
+    int   lda, ldb, ldo;
+    int   k_chunk;               // K range handled by one blockIdx.z
+    long long slab_stride;       // floats between the outputs of consecutive blockIdx.z
+    float alpha;
+    const float* alpha_ptr;      // optional device scalar multiplied into alpha (logit scale)
+    // TB==1 only: reduction rows k >= k_switch come from a second table (text rows
+    // follow image rows in dZ^T); rows outside [0,k_valid) of either part are zeros.
+    const float*   B2;
+    const int64_t* k_rows2;
+    int   ldb2;
+    int   k_switch;
+    int   k_valid1, k_valid2;
+};
+
+struct OptArgs {
+    int   kind;                  // UMLH_OPT_*
+    float lr, decay;             // decay = 1 - lr*wd (AdamW)
+    float neg_step_size;         // -(lr / (1 - beta1^t))
+    float bc2_sqrt;              // sqrt(1 - beta2^t)
+    float beta1, one_m_beta1, beta2, one_m_beta2, eps, momentum, wd;
+};
+
+struct FinalizeArgs {
+    const float* partials;       // fwd partials, or NULL when the tail is already final
+    int   nb0, nb1;              // blocks of segment 0 / 1
+    float inv_rows0, inv_rows1;  // 1 / global rows
+    float w0, w1;                // loss weights (img_alpha, alpha)
+    float* tail;                 // [2 + UMLH_N_SCALARS]: g_scales, scalars
+    float* scalars_out;          // optional copy of the scalars
+    float* scales; float* m_scales; float* v_scales;   // [2]
+    int   update_mask;           // bit0: update img_scale, bit1: txt_scale
+    OptArgs opt;
+};
+
+// torch.optim single-tensor update of one element (see oracle/uml_oracle.py
+// optimizer_step for the restated recurrence and its reference citations).
+__device__ __forceinline__ void opt_update(const OptArgs& o, float g, float& p, float& m, float& v) {
+    if (o.kind == UMLH_OPT_SGD) {
+        if (o.wd != 0.f) g = g + o.wd * p;
+        m = o.momentum * m + g;
+        p = p - o.lr * m;
+    } else {
+        if (o.kind == UMLH_OPT_ADAMW) p = p * o.decay;
+        else if (o.wd != 0.f) g = g + o.wd * p;
+        m = m + (g - m) * o.one_m_beta1;
+        v = v * o.beta2 + (o.one_m_beta2 * g) * g;
+        float denom = sqrtf(v) / o.bc2_sqrt + o.eps;
+        p = p + (o.neg_step_size * m) / denom;
+    }
+}

@@ -1,0 +1,609 @@
+// fp32 (parity-mode) kernels of the UML head step for gfx950.
+//
+// All matrix work runs on the f32-input MFMA v_mfma_f32_32x32x2_f32, which is
+// bit-for-bit a k-ordered fp32 fma chain (MI355X guide, "FP32-input MFMA"), so
+// logits/loss/gradients agree with the reference's fp32 PyTorch path to fp32
+// reduction-order noise (<1e-4 on logits, the north_star tolerance).
+//
+//   fwd_ce_f32     fused  features x W^T * scale -> softmax-CE -> dZ^T, per-row
+//                  loss / top-1 / d(scale)   (head.py:77-84, finetune.py:186-188,197-198)
+//   gemm_f32       generic tiled GEMM with row gathers and split-K slabs: img_proj
+//                  forward, dW = dZ^T F, dH^T = W^T dZ^T, dW_proj = dH^T X
+//   reduce_update  sum split-K slabs (+ optimizer step in the same pass)
+//   finalize       per-step scalars + the two learnable logit scales
+//   zero_shot      head.py:22-37
+#include "umlh_common.h"
+
+// --------------------------------------------------------------------------- //
+// staging helpers: global -> registers -> LDS, k-major LDS tiles [KT][LD]
+// --------------------------------------------------------------------------- //
+// Load 4 consecutive floats p[0..3] with element guards lim (number of valid
+// elements from p, may be <= 0); vector path when 16-B aligned and fully valid.
+__device__ __forceinline__ f32x4v load4_guard(const float* p, int lim, bool vec_ok) {
+    f32x4v v = {0.f, 0.f, 0.f, 0.f};
+    if (lim >= 4 && vec_ok) {
+        v = *reinterpret_cast<const f32x4v*>(p);
+    } else {
+        if (lim > 0) v[0] = p[0];
+        if (lim > 1) v[1] = p[1];
+        if (lim > 2) v[2] = p[2];
+        if (lim > 3) v[3] = p[3];
+    }
+    return v;
+}
+
+// --------------------------------------------------------------------------- //
+// fused forward + cross entropy
+// --------------------------------------------------------------------------- //
+// Workgroup = 8 waves = WC (class direction) x WS (sample direction).  The MFMA is
+// issued "swapped" (A = W class tile, B = X sample tile) so that every lane owns ONE
+// sample (column) and 16*CTW of its class logits (rows) in registers: the softmax
+// reductions over classes are in-lane, then one half-swap, then WC values via LDS.
+template <int CTW, int WC>
+__global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
+    constexpr int WS = 8 / WC;
+    constexpr int CPAD = 32 * CTW * WC;
+    constexpr int TS = 32 * WS;
+    constexpr int LDW = CPAD + 4;
+    constexpr int LDX = TS + 4;
+    constexpr int NPW = (CPAD * 4 + 511) / 512;     // float4 pieces of W per thread
+    constexpr int NPX = (TS * 4 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;                     // [KT][LDW]
+    float* Xs = Ws + KT * LDW;            // [KT][LDX]
+    float* red = Xs + KT * LDX;           // [WC][TS][4]
+    float* red2 = red + WC * TS * 4;      // [WS][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave % WC, ws = wave / WC;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int sidx = (int)blockIdx.x >= a.seg[1].blk0 ? 1 : 0;
+    const SegDesc& sg = a.seg[sidx];
+    const int row0 = ((int)blockIdx.x - sg.blk0) * TS;
+    const int C = a.C, K = a.K;
+    const bool vecW = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
+    const bool vecX = (sg.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.feats) & 15) == 0);
+
+    // per-thread source rows (hoisted out of the K loop)
+    const float* wsrc[NPW];
+    const float* xsrc[NPX];
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+        int p = tid + 512 * q, cls = p >> 2;
+        wsrc[q] = (p < CPAD * 4 && cls < C) ? a.W + (size_t)cls * K : nullptr;
+    }
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+        int p = tid + 512 * q, smp = p >> 2, r = row0 + smp;
+        const float* s = nullptr;
+        if (p < TS * 4 && r < sg.rows) {
+            int64_t rid = sg.feat_index ? sg.feat_index[r] : (int64_t)r;
+            s = sg.feats + (size_t)rid * sg.ld;
+        }
+        xsrc[q] = s;
+    }
+
+    f32x16 acc[CTW];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+
+    f32x4v wreg[NPW], xreg[NPX];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NPW; ++q) {
+            int g = (tid + 512 * q) & 3;
+            int k = k0 + 4 * g;
+            wreg[q] = wsrc[q] ? load4_guard(wsrc[q] + k, K - k, vecW) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) {
+            int g = (tid + 512 * q) & 3;
+            int k = k0 + 4 * g;
+            xreg[q] = xsrc[q] ? load4_guard(xsrc[q] + k, K - k, vecX) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NPW; ++q) {
+            int p = tid + 512 * q;
+            if (p < CPAD * 4) {
+                int cls = p >> 2, g = p & 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ws[(4 * g + j) * LDW + cls] = wreg[q][j];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) {
+            int p = tid + 512 * q;
+            if (p < TS * 4) {
+                int smp = p >> 2, g = p & 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Xs[(4 * g + j) * LDX + smp] = xreg[q][j];
+            }
+        }
+    };
+
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += KT) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (k0 + KT < K) gload(k0 + KT);
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; ++kk) {
+            const int krow = 2 * kk + h;
+            const float b = Xs[krow * LDX + ws * 32 + l31];
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+                const float av = Ws[krow * LDW + (wc * CTW + ct) * 32 + l31];
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[ct], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---------------- epilogue: softmax cross entropy on the register tile ----------------
+    const float scale = *sg.scale_ptr;
+    const int smp = ws * 32 + l31;
+    const int r = row0 + smp;
+    const bool valid = r < sg.rows;
+    int lab = -1;
+    if (valid) lab = (int)sg.labels[sg.label_index ? sg.label_index[r] : (int64_t)r];
+
+    const float NEG_INF = -__builtin_huge_valf();
+    float mx = NEG_INF;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
+            float v = cls < C ? acc[ct][i] * scale : NEG_INF;
+            if (v > mx) { mx = v; mi = cls; }
+        }
+    {
+        float omx = __shfl_xor(mx, 32);
+        int omi = __shfl_xor(mi, 32);
+        if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+    }
+    if (WC > 1) {
+        if (h == 0) { red[(wc * TS + smp) * 4 + 0] = mx; red[(wc * TS + smp) * 4 + 1] = __int_as_float(mi); }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < WC; ++w) {
+            float omx = red[(w * TS + smp) * 4 + 0];
+            int omi = __float_as_int(red[(w * TS + smp) * 4 + 1]);
+            if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+        }
+        __syncthreads();
+    }
+
+    float se = 0.f, serw = 0.f, zy = 0.f, rawy = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
+            float raw = acc[ct][i];
+            float e = cls < C ? expf(raw * scale - mx) : 0.f;
+            se += e;
+            serw += e * raw;
+            if (cls == lab) { zy = raw * scale; rawy = raw; }
+            acc[ct][i] = e;                 // keep exp() for the dZ pass
+        }
+    se += __shfl_xor(se, 32);
+    serw += __shfl_xor(serw, 32);
+    zy += __shfl_xor(zy, 32);
+    rawy += __shfl_xor(rawy, 32);
+    if (WC > 1) {
+        if (h == 0) {
+            float* d = red + (wc * TS + smp) * 4;
+            d[0] = se; d[1] = serw; d[2] = zy; d[3] = rawy;
+        }
+        __syncthreads();
+        se = serw = zy = rawy = 0.f;
+#pragma unroll
+        for (int w = 0; w < WC; ++w) {
+            const float* d = red + (w * TS + smp) * 4;
+            se += d[0]; serw += d[1]; zy += d[2]; rawy += d[3];
+        }
+    }
+
+    if (a.dzt != nullptr && valid) {
+        const float coef = sg.w_over_rows * scale;
+        const float inv = 1.f / se;
+        float* dst = a.dzt + sg.col0 + r;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
+                if (cls < C) {
+                    float p = acc[ct][i] * inv;
+                    dst[(size_t)cls * a.ldz] = (p - (cls == lab ? 1.f : 0.f)) * coef;
+                }
+            }
+    }
+
+    // per-block sums of loss / top-1 / d(scale), taken once per sample (wc==0, h==0 lanes)
+    float vl = 0.f, vc = 0.f, vg = 0.f;
+    if (wc == 0 && h == 0 && valid) {
+        vl = logf(se) + mx - zy;
+        vc = (mi == lab) ? 1.f : 0.f;
+        vg = serw / se - rawy;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        vl += __shfl_xor(vl, off);
+        vc += __shfl_xor(vc, off);
+        vg += __shfl_xor(vg, off);
+    }
+    if (wc == 0 && lane == 0) { red2[ws * 4 + 0] = vl; red2[ws * 4 + 1] = vc; red2[ws * 4 + 2] = vg; }
+    __syncthreads();
+    if (tid == 0) {
+        float l = 0.f, c = 0.f, g = 0.f;
+#pragma unroll
+        for (int w = 0; w < WS; ++w) { l += red2[w * 4 + 0]; c += red2[w * 4 + 1]; g += red2[w * 4 + 2]; }
+        float* o = a.partials + (size_t)blockIdx.x * 4;
+        o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// generic GEMM  out[m][n] = alpha * sum_k A(m,k) B(n,k), 128x128 tile, 4 waves (2x2),
+// each wave 64x64 = 2x2 MFMA tiles.  TA/TB = 0: operand stored with k contiguous
+// (A[m*lda+k]);  = 1: stored k-major (A[k*lda+m]).  blockIdx.z = split-K slab.
+// --------------------------------------------------------------------------- //
+constexpr int GBM = 128, GBN = 128, GLD = 132;
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[KT * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[KT * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int kb = blockIdx.z * g.k_chunk;
+    const int ke = min(g.K, kb + g.k_chunk);
+
+    auto kvalid = [&](int k) -> bool {
+        return k < g.k_switch ? (k < g.k_valid1) : (k - g.k_switch < g.k_valid2);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4v areg[2], breg[2];
+    // ---- A ----
+    const float* a_src[2];
+    const bool vecA = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+    if (TA == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int p = tid + 256 * q, row = p >> 2, m = m0 + row;
+            const float* s = nullptr;
+            if (m < g.M) {
+                int64_t rid = g.a_rows ? g.a_rows[m] : (int64_t)m;
+                s = g.A + (size_t)rid * g.lda;
+            }
+            a_src[q] = s;
+        }
+    }
+    const bool vecB = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+    const bool vecB2 = TB == 1 && g.B2 && (g.ldb2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B2) & 15) == 0);
+    const float* b_src[2];
+    if (TB == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int p = tid + 256 * q, row = p >> 2, n = n0 + row;
+            b_src[q] = n < g.N ? g.B + (size_t)n * g.ldb : nullptr;
+        }
+    }
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int p = tid + 256 * q;
+            if (TA == 0) {                       // piece = (row m, 4 consecutive k)
+                int k = k0 + 4 * (p & 3);
+                f32x4v v = a_src[q] ? load4_guard(a_src[q] + k, ke - k, vecA) : f32x4v{0.f, 0.f, 0.f, 0.f};
+                if (TB == 1) {                   // reduction index is a dZ^T column: mask padding
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (!kvalid(k + j)) v[j] = 0.f;
+                }
+                areg[q] = v;
+            } else {                             // piece = (k row, 4 consecutive m)
+                int kk = p >> 5, mm = m0 + 4 * (p & 31), k = k0 + kk;
+                areg[q] = (k < ke) ? load4_guard(g.A + (size_t)k * g.lda + mm, g.M - mm, vecA)
+                                   : f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+            if (TB == 0) {
+                int k = k0 + 4 * (p & 3);
+                breg[q] = b_src[q] ? load4_guard(b_src[q] + k, ke - k, vecB) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            } else {
+                int kk = p >> 5, nn = n0 + 4 * (p & 31), k = k0 + kk;
+                f32x4v v = {0.f, 0.f, 0.f, 0.f};
+                if (k < ke && kvalid(k)) {
+                    if (k < g.k_switch) {
+                        int64_t rid = g.k_rows ? g.k_rows[k] : (int64_t)k;
+                        v = load4_guard(g.B + (size_t)rid * g.ldb + nn, g.N - nn, vecB);
+                    } else {
+                        int kl = k - g.k_switch;
+                        int64_t rid = g.k_rows2 ? g.k_rows2[kl] : (int64_t)kl;
+                        v = load4_guard(g.B2 + (size_t)rid * g.ldb2 + nn, g.N - nn, vecB2);
+                    }
+                }
+                breg[q] = v;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int p = tid + 256 * q;
+            if (TA == 0) {
+                int row = p >> 2, gq = p & 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[(4 * gq + j) * GLD + row] = areg[q][j];
+            } else {
+                int kk = p >> 5, mm = 4 * (p & 31);
+                *reinterpret_cast<f32x4v*>(&As[kk * GLD + mm]) = areg[q];
+            }
+            if (TB == 0) {
+                int row = p >> 2, gq = p & 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(4 * gq + j) * GLD + row] = breg[q][j];
+            } else {
+                int kk = p >> 5, nn = 4 * (p & 31);
+                *reinterpret_cast<f32x4v*>(&Bs[kk * GLD + nn]) = breg[q];
+            }
+        }
+    };
+
+    if (kb < ke) gload(kb);
+    for (int k0 = kb; k0 < ke; k0 += KT) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (k0 + KT < ke) gload(k0 + KT);
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; ++kk) {
+            const int krow = 2 * kk + h;
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = As[krow * GLD + wm * 64 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Bs[krow * GLD + wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* out = g.out + (size_t)blockIdx.z * g.slab_stride;
+    const float alpha = g.alpha * (g.alpha_ptr ? *g.alpha_ptr : 1.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int m = m0 + wm * 64 + i * 32 + acc_row(e, h);
+                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][j][e] * alpha;
+            }
+        }
+}
+
+// --------------------------------------------------------------------------- //
+// slab reduction (+ optimizer update)
+// --------------------------------------------------------------------------- //
+// MODE 0: grad_out = sum of slabs.  MODE 1: p,m,v updated from the sum (grad_out
+// optional).  n = number of parameters (multiple of 4 not required).
+template <int MODE>
+__global__ __launch_bounds__(256) void reduce_update(const float* __restrict__ slabs, int n_slabs,
+                                                     long long slab_stride, long long n,
+                                                     float* __restrict__ grad_out, float* __restrict__ p,
+                                                     float* __restrict__ m, float* __restrict__ v, OptArgs o) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n && (slab_stride % 4 == 0)) {
+        f32x4v gsum = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < n_slabs; ++s)
+            gsum += *reinterpret_cast<const f32x4v*>(slabs + (size_t)s * slab_stride + i);
+        if (grad_out) *reinterpret_cast<f32x4v*>(grad_out + i) = gsum;
+        if (MODE == 1) {
+            f32x4v pp = *reinterpret_cast<f32x4v*>(p + i);
+            f32x4v mm = *reinterpret_cast<f32x4v*>(m + i);
+            f32x4v vv = {0.f, 0.f, 0.f, 0.f};
+            if (o.kind != UMLH_OPT_SGD) vv = *reinterpret_cast<f32x4v*>(v + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = pp[j], b = mm[j], c = vv[j];
+                opt_update(o, gsum[j], a, b, c);
+                pp[j] = a; mm[j] = b; vv[j] = c;
+            }
+            *reinterpret_cast<f32x4v*>(p + i) = pp;
+            *reinterpret_cast<f32x4v*>(m + i) = mm;
+            if (o.kind != UMLH_OPT_SGD) *reinterpret_cast<f32x4v*>(v + i) = vv;
+        }
+    } else {
+        for (long long e = i; e < n && e < i + 4; ++e) {
+            float gs = 0.f;
+            for (int s = 0; s < n_slabs; ++s) gs += slabs[(size_t)s * slab_stride + e];
+            if (grad_out) grad_out[e] = gs;
+            if (MODE == 1) {
+                float a = p[e], b = m[e], c = (o.kind != UMLH_OPT_SGD) ? v[e] : 0.f;
+                opt_update(o, gs, a, b, c);
+                p[e] = a; m[e] = b;
+                if (o.kind != UMLH_OPT_SGD) v[e] = c;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// per-step scalars + logit-scale parameters
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
+    __shared__ float sh[6][256];
+    const int tid = threadIdx.x;
+    if (f.partials != nullptr) {
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = tid; b < f.nb0 + f.nb1; b += 256) {
+            const float* q = f.partials + (size_t)b * 4;
+            int o = b < f.nb0 ? 0 : 3;
+            s[o + 0] += q[0]; s[o + 1] += q[1]; s[o + 2] += q[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sh[j][tid] = s[j];
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) sh[j][tid] += sh[j][tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            float* t = f.tail;
+            t[0] = sh[2][0] * f.w0 * f.inv_rows0;                    // d loss / d img_scale
+            t[1] = sh[5][0] * f.w1 * f.inv_rows1;                    // d loss / d txt_scale
+            float* sc = t + 2;
+            sc[UMLH_S_LOSS_IMG] = sh[0][0] * f.inv_rows0;
+            sc[UMLH_S_LOSS_TXT] = sh[3][0] * f.inv_rows1;
+            sc[UMLH_S_ACC_IMG] = sh[1][0] * f.inv_rows0;
+            sc[UMLH_S_ACC_TXT] = sh[4][0] * f.inv_rows1;
+            sc[UMLH_S_GSCALE_IMG] = t[0];
+            sc[UMLH_S_GSCALE_TXT] = t[1];
+            sc[UMLH_S_CORRECT] = sh[1][0] + sh[4][0];
+            sc[UMLH_S_LOSS_SUM] = sh[0][0] + sh[3][0];
+        }
+        __syncthreads();
+    }
+    if (tid < UMLH_N_SCALARS && f.scalars_out) f.scalars_out[tid] = f.tail[2 + tid];
+    if (tid < 2 && ((f.update_mask >> tid) & 1)) {
+        float p = f.scales[tid], m = f.m_scales[tid], v = f.v_scales[tid];
+        opt_update(f.opt, f.tail[tid], p, m, v);
+        f.scales[tid] = p; f.m_scales[tid] = m; f.v_scales[tid] = v;
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// zero-shot head init: one block per class, rows visited in index order
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void zero_shot_kernel(const float* __restrict__ feats,
+                                                        const int64_t* __restrict__ labels, long long n, int d,
+                                                        float* __restrict__ w) {
+    extern __shared__ float zsum[];          // [d] + [256]
+    float* redn = zsum + d;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < d; j += 256) zsum[j] = 0.f;
+    int count = 0;
+    for (long long r = 0; r < n; ++r) {
+        if (labels[r] == c) {
+            ++count;
+            for (int j = tid; j < d; j += 256) zsum[j] += feats[(size_t)r * d + j];
+        }
+    }
+    float ss = 0.f;
+    for (int j = tid; j < d; j += 256) {
+        float mean = count > 0 ? zsum[j] / (float)count : 0.f;
+        zsum[j] = mean;
+        ss += mean * mean;
+    }
+    redn[tid] = ss;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) redn[tid] += redn[tid + off];
+        __syncthreads();
+    }
+    float nrm = fmaxf(sqrtf(redn[0]), 1e-12f);
+    for (int j = tid; j < d; j += 256) w[(size_t)c * d + j] = zsum[j] / nrm;
+}
+
+// --------------------------------------------------------------------------- //
+// launchers (called from umlh_api.cpp)
+// --------------------------------------------------------------------------- //
+extern "C" {
+
+// fwd_ce configuration for a class count: WC waves along classes, CTW 32-class
+// tiles per wave.  Returns samples per block (TS) or 0 if C is unsupported.
+int umlh_f32_fwd_config(int C, int* ctw, int* wc) {
+    if (C < 1 || C > 1024) return 0;
+    int tiles = (C + 31) / 32;
+    int w = 1;
+    while (w < tiles && w < 8) w *= 2;
+    int t = (tiles + w - 1) / w;
+    if (t == 3) t = 4;
+    *ctw = t; *wc = w;
+    return 32 * (8 / w);
+}
+
+static size_t fwd_smem_bytes(int ctw, int wc) {
+    int ws = 8 / wc, cpad = 32 * ctw * wc, ts = 32 * ws;
+    return sizeof(float) * (size_t)(KT * (cpad + 4) + KT * (ts + 4) + wc * ts * 4 + ws * 4 + 16);
+}
+
+#define FWD_CASE(CT, W)                                                                             \
+    if (ctw == CT && wc == W) {                                                                     \
+        size_t sm = fwd_smem_bytes(CT, W);                                                          \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_f32<CT, W>),       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);    \
+        if (e != hipSuccess) return (int)e;                                                         \
+        hipLaunchKernelGGL((fwd_ce_f32<CT, W>), dim3(grid), dim3(512), sm, stream, *a);             \
+        return (int)hipGetLastError();                                                              \
+    }
+
+int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t stream) {
+    if (grid <= 0) return 0;
+    FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(1, 8) FWD_CASE(2, 8) FWD_CASE(4, 8)
+    return (int)hipErrorInvalidValue;
+}
+
+int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream) {
+    if (g->M <= 0 || g->N <= 0) return 0;
+    dim3 grid((g->N + GBN - 1) / GBN, (g->M + GBM - 1) / GBM, splits);
+    if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_f32<0, 0>), grid, dim3(256), 0, stream, *g);
+    else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_f32<0, 1>), grid, dim3(256), 0, stream, *g);
+    else if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_f32<1, 1>), grid, dim3(256), 0, stream, *g);
+    else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long long slab_stride, long long n,
+                              float* grad_out, float* p, float* m, float* v, const OptArgs* o,
+                              hipStream_t stream) {
+    if (n <= 0) return 0;
+    int blocks = (int)((n + 1023) / 1024);
+    if (mode == 0)
+        hipLaunchKernelGGL((reduce_update<0>), dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, n,
+                           grad_out, p, m, v, *o);
+    else
+        hipLaunchKernelGGL((reduce_update<1>), dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, n,
+                           grad_out, p, m, v, *o);
+    return (int)hipGetLastError();
+}
+
+int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, *f);
+    return (int)hipGetLastError();
+}
+
+int umlh_launch_zero_shot(const float* feats, const int64_t* labels, long long n, int d, int C, float* w,
+                          hipStream_t stream) {
+    size_t sm = sizeof(float) * (size_t)(d + 256);
+    hipLaunchKernelGGL(zero_shot_kernel, dim3(C), dim3(256), sm, stream, feats, labels, n, d, w);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

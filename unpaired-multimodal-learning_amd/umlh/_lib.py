@@ -1,0 +1,117 @@
+"""ctypes binding of include/umlh.h + the in-tree hipcc build of libumlh.so."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+_ROOT = os.path.dirname(_PKG)
+_CSRC = os.path.join(_PKG, "csrc")
+_INCLUDE = os.path.join(_ROOT, "include")
+_SO = os.path.join(_HERE, "libumlh.so")
+
+OPT_IDS = {"sgd": 0, "adam": 1, "adamw": 2}          # engine/optimizer/optim.py:6 AVAI_OPTIMS
+PREC_IDS = {"fp32": 0, "bf16": 1}
+(S_LOSS_IMG, S_LOSS_TXT, S_ACC_IMG, S_ACC_TXT, S_GSCALE_IMG, S_GSCALE_TXT, S_CORRECT, S_LOSS_SUM) = range(8)
+N_SCALARS = 8
+
+SOURCES = ["umlh_kernels_f32.hip", "umlh_api.cpp"]
+EXPORTS = ["umlh_last_error", "umlh_version", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
+           "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
+           "umlh_apply_update", "umlh_eval_batch"]
+
+
+class UmlhError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("d_img", C.c_int32), ("d_shared", C.c_int32), ("num_classes", C.c_int32),
+                ("has_proj", C.c_int32), ("learnable_temp", C.c_int32), ("optimizer", C.c_int32),
+                ("precision", C.c_int32), ("max_rows_img", C.c_int32), ("max_rows_txt", C.c_int32),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("momentum", C.c_double),
+                ("weight_decay", C.c_double)]
+
+
+class Buffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_head", "m_head", "v_head", "w_proj", "m_proj", "v_proj",
+                                          "scales", "m_scales", "v_scales", "workspace")] + \
+               [("workspace_bytes", C.c_uint64)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("feats", C.c_void_p), ("labels", C.c_void_p), ("index", C.c_void_p),
+                ("rows", C.c_int32), ("global_rows", C.c_int32)]
+
+
+class Hyper(C.Structure):
+    _fields_ = [("lr", C.c_double), ("step", C.c_int64), ("alpha", C.c_float), ("img_alpha", C.c_float)]
+
+
+def lib_path() -> str:
+    return _SO
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compile the HIP sources for gfx950 into umlh/libumlh.so (in-tree, so the
+    binary travels with the repo snapshot to the GPU box)."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(_CSRC, "umlh_common.h"), os.path.join(_INCLUDE, "umlh.h")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
+        return _SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", _INCLUDE, "-I", _CSRC, *srcs, "-o", _SO + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise UmlhError(f"hipcc failed ({res.returncode}):\n{res.stderr[-4000:]}")
+    os.replace(_SO + ".tmp", _SO)
+    return _SO
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen libumlh.so and declare every prototype of include/umlh.h.  Raises
+    UmlhError if the extension has not been built: there is no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise UmlhError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). The HIP extension is mandatory; there is no CPU fallback.")
+    lib = C.CDLL(_SO)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    lib.umlh_last_error.restype = C.c_char_p
+    lib.umlh_last_error.argtypes = []
+    lib.umlh_version.restype = C.c_int
+    lib.umlh_workspace_bytes.restype = u64
+    lib.umlh_workspace_bytes.argtypes = [C.POINTER(Config)]
+    lib.umlh_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.umlh_destroy.argtypes = [vp]
+    lib.umlh_bind.argtypes = [vp, C.POINTER(Buffers)]
+    lib.umlh_zero_shot_init.argtypes = [vp, vp, vp, i64, vp]
+    lib.umlh_logits.argtypes = [vp, C.POINTER(Batch), C.c_int, vp, vp]
+    lib.umlh_train_step.argtypes = [vp, C.POINTER(Batch), C.POINTER(Batch), C.POINTER(Hyper), vp, vp]
+    lib.umlh_grad_step.argtypes = [vp, C.POINTER(Batch), C.POINTER(Batch), C.POINTER(Hyper), vp]
+    lib.umlh_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.umlh_apply_update.argtypes = [vp, C.POINTER(Hyper), vp, vp]
+    lib.umlh_eval_batch.argtypes = [vp, C.POINTER(Batch), vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("umlh_last_error", "umlh_workspace_bytes"):
+            fn.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load_library().umlh_last_error()
+        raise UmlhError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

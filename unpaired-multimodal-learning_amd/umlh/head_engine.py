@@ -1,0 +1,189 @@
+"""HeadEngine: torch-owned buffers + one umlh handle = the fused UML head step.
+
+Host-side plumbing only (device memory, streams); all arithmetic happens in the
+HIP kernels behind the C ABI.  Mirrors what ``finetune.train`` does per step
+with ``model``/``optimizer`` (vision_language/finetune.py:180-195).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import Batch, Buffers, Config, Hyper, OPT_IDS, PREC_IDS, N_SCALARS, UmlhError, check
+
+
+@dataclass
+class RowBatch:
+    """Rows of one modality for one step: a device-resident (feats, labels) table and
+    optional int64 row ids into it (None = rows 0..rows-1)."""
+    feats: torch.Tensor                 # [N, dim] fp32, device, contiguous
+    labels: torch.Tensor                # [N] int64, device
+    index: Optional[torch.Tensor] = None  # [rows] int64, device
+    rows: Optional[int] = None
+    global_rows: Optional[int] = None   # CE-mean denominator across ranks (default = rows)
+
+    def n_rows(self) -> int:
+        if self.rows is not None:
+            return int(self.rows)
+        return int(self.index.numel() if self.index is not None else self.feats.shape[0])
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HeadEngine:
+    def __init__(self, d_img: int, d_shared: int, num_classes: int, *, has_proj: bool = False,
+                 learnable_temp: bool = False, optimizer: str = "adamw", weight_decay: float = 0.0,
+                 betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9,
+                 max_rows_img: int = 4096, max_rows_txt: int = 4096, precision: str = "fp32",
+                 device="cuda:0"):
+        if optimizer not in OPT_IDS:   # engine/optimizer/optim.py:22
+            raise AssertionError(f"Optimizer {optimizer} not found; available optimizers = {list(OPT_IDS)}")
+        self.lib = _lib.load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise UmlhError("HeadEngine needs a GPU device (gfx950); there is no CPU path")
+        self.cfg = Config(d_img, d_shared, num_classes, int(has_proj), int(learnable_temp), OPT_IDS[optimizer],
+                          PREC_IDS[precision], max_rows_img, max_rows_txt, betas[0], betas[1], eps, momentum,
+                          weight_decay)
+        nbytes = int(self.lib.umlh_workspace_bytes(C.byref(self.cfg)))
+        if nbytes == 0:
+            raise UmlhError(f"unsupported head config: d_img={d_img} d_shared={d_shared} C={num_classes} "
+                            f"has_proj={has_proj} precision={precision}")
+        self.handle = C.c_void_p()
+        check(self.lib.umlh_create(C.byref(self.cfg), C.byref(self.handle)), "umlh_create")
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.workspace = torch.empty(nbytes // 4, **f32)
+        self.has_proj, self.learnable_temp, self.optimizer = bool(has_proj), bool(learnable_temp), optimizer
+        self.d_img, self.d_shared, self.num_classes = d_img, d_shared, num_classes
+        self.w_head = torch.zeros(num_classes, d_shared, **f32)
+        self.m_head = torch.zeros_like(self.w_head)
+        self.v_head = torch.zeros_like(self.w_head)
+        self.w_proj = torch.zeros(d_shared, d_img, **f32) if has_proj else None
+        self.m_proj = torch.zeros_like(self.w_proj) if has_proj else None
+        self.v_proj = torch.zeros_like(self.w_proj) if has_proj else None
+        self.scales = torch.ones(2, **f32)
+        self.m_scales = torch.zeros(2, **f32)
+        self.v_scales = torch.zeros(2, **f32)
+        self._scalars = torch.zeros(N_SCALARS, **f32)
+        self.rebind()
+
+    # -- buffers -----------------------------------------------------------------
+    def rebind(self, **tensors) -> None:
+        """(Re)attach parameter/state tensors, e.g. ``rebind(w_head=model.head.weight.data)``
+        so the kernels update the module's own storage in place."""
+        for k, v in tensors.items():
+            if not hasattr(self, k):
+                raise KeyError(k)
+            if v is not None:
+                cur = getattr(self, k)
+                if v.dtype != torch.float32 or not v.is_contiguous() or v.device != self.device:
+                    raise UmlhError(f"rebind({k}): need a contiguous fp32 tensor on {self.device}")
+                if cur is not None and tuple(cur.shape) != tuple(v.shape):
+                    raise UmlhError(f"rebind({k}): shape {tuple(v.shape)} != {tuple(cur.shape)}")
+            setattr(self, k, v)
+        b = Buffers(_ptr(self.w_head), _ptr(self.m_head), _ptr(self.v_head), _ptr(self.w_proj), _ptr(self.m_proj),
+                    _ptr(self.v_proj), _ptr(self.scales), _ptr(self.m_scales), _ptr(self.v_scales),
+                    _ptr(self.workspace), self.workspace.numel() * 4)
+        check(self.lib.umlh_bind(self.handle, C.byref(b)), "umlh_bind")
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.umlh_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _batch(self, b: Optional[RowBatch], dim: int) -> Optional[Batch]:
+        if b is None:
+            return None
+        rows = b.n_rows()
+        if rows == 0:
+            return None
+        f, y = b.feats, b.labels
+        if f.dtype != torch.float32 or not f.is_contiguous() or f.dim() != 2 or f.shape[1] != dim:
+            raise UmlhError(f"features must be contiguous fp32 [N,{dim}], got {f.dtype} {tuple(f.shape)}")
+        if y.dtype != torch.int64 or not y.is_contiguous():
+            raise UmlhError("labels must be contiguous int64")
+        if f.device != self.device or y.device != self.device:
+            raise UmlhError(f"features/labels must live on {self.device}")
+        if b.index is not None:
+            if b.index.dtype != torch.int64 or not b.index.is_contiguous() or b.index.device != self.device:
+                raise UmlhError("index must be contiguous int64 on the engine's device")
+            if b.index.numel() < rows:
+                raise UmlhError("index shorter than rows")
+        elif f.shape[0] < rows:
+            raise UmlhError("feature table shorter than rows")
+        return Batch(_ptr(f), _ptr(y), _ptr(b.index), rows, int(b.global_rows or rows))
+
+    @staticmethod
+    def _ref(x):
+        return None if x is None else C.byref(x)
+
+    # -- C ABI calls -----------------------------------------------------------------
+    def zero_shot_init(self, text_feats: torch.Tensor, text_labels: torch.Tensor) -> None:
+        """head.weight.data = get_zero_shot_weights(...)  (engine/models/head.py:22-37,96-98)."""
+        tf = text_feats.to(self.device, torch.float32).contiguous()
+        tl = text_labels.to(self.device, torch.int64).contiguous()
+        if tf.shape[1] != self.d_shared:
+            raise UmlhError(f"text features have dim {tf.shape[1]}, head expects {self.d_shared}")
+        check(self.lib.umlh_zero_shot_init(self.handle, _ptr(tf), _ptr(tl), tf.shape[0], self._stream()),
+              "umlh_zero_shot_init")
+        torch.cuda.current_stream(self.device).synchronize()   # tf/tl are temporaries
+
+    def logits(self, batch: RowBatch, modality: int) -> torch.Tensor:
+        dim = self.d_img if modality == 0 else self.d_shared
+        b = self._batch(batch, dim)
+        out = torch.empty(batch.n_rows(), self.num_classes, dtype=torch.float32, device=self.device)
+        if b is not None:
+            check(self.lib.umlh_logits(self.handle, C.byref(b), modality, _ptr(out), self._stream()), "umlh_logits")
+        return out
+
+    def train_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], lr: float, step: int,
+                   alpha: float = 1.0, img_alpha: float = 1.0, scalars_out: Optional[torch.Tensor] = None):
+        bi, bt = self._batch(img, self.d_img), self._batch(txt, self.d_shared)
+        hy = Hyper(float(lr), int(step), float(alpha), float(img_alpha))
+        so = scalars_out if scalars_out is not None else self._scalars
+        check(self.lib.umlh_train_step(self.handle, self._ref(bi), self._ref(bt), C.byref(hy), _ptr(so),
+                                       self._stream()), "umlh_train_step")
+        return so
+
+    def grad_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], alpha: float = 1.0,
+                  img_alpha: float = 1.0) -> torch.Tensor:
+        bi, bt = self._batch(img, self.d_img), self._batch(txt, self.d_shared)
+        hy = Hyper(0.0, 1, float(alpha), float(img_alpha))
+        check(self.lib.umlh_grad_step(self.handle, self._ref(bi), self._ref(bt), C.byref(hy), self._stream()),
+              "umlh_grad_step")
+        return self.grad_buffer()
+
+    def grad_buffer(self) -> torch.Tensor:
+        """Flat fp32 view [g_head | g_proj | g_scales(2) | scalars(8)] inside the workspace."""
+        p, n = C.c_void_p(), C.c_uint64()
+        check(self.lib.umlh_grad_buffer(self.handle, C.byref(p), C.byref(n)), "umlh_grad_buffer")
+        off = (p.value - self.workspace.data_ptr()) // 4
+        return self.workspace[off:off + n.value]
+
+    def apply_update(self, lr: float, step: int, scalars_out: Optional[torch.Tensor] = None):
+        hy = Hyper(float(lr), int(step), 1.0, 1.0)
+        so = scalars_out if scalars_out is not None else self._scalars
+        check(self.lib.umlh_apply_update(self.handle, C.byref(hy), _ptr(so), self._stream()), "umlh_apply_update")
+        return so
+
+    def eval_batch(self, batch: RowBatch, scalars_out: Optional[torch.Tensor] = None):
+        b = self._batch(batch, self.d_img)
+        so = scalars_out if scalars_out is not None else self._scalars
+        check(self.lib.umlh_eval_batch(self.handle, self._ref(b), _ptr(so), self._stream()), "umlh_eval_batch")
+        return so
