@@ -127,6 +127,10 @@ int  umlh_zero_shot_init(umlh_handle_t h, const float* text_feats, const int64_t
  * logits_out: device [rows, C] fp32. */
 int  umlh_logits(umlh_handle_t h, const umlh_batch_t* batch, int modality, float* logits_out, void* stream);
 
+/* model.extract_features(images) for the projected head: out[rows, d_shared] =
+ * img_proj(feats) (head.py:87-90).  Requires has_proj. */
+int  umlh_project(umlh_handle_t h, const umlh_batch_t* batch, float* out, void* stream);
+
 /* One whole training step (finetune.py:180-195 minus logging): fused
  * features x W^T * scale -> softmax-CE -> dZ, dW(+dW_proj, dscale), optimizer
  * update of every parameter.  Either batch may have rows == 0 (modality absent,
@@ -148,6 +152,13 @@ int  umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hyper, float* scalar
  * scalars_out[UMLH_S_LOSS_SUM] (sum of row losses); the caller forms the
  * per-batch means (finetune.py:311-312). */
 int  umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* batch, float* scalars_out, void* stream);
+
+/* Standalone optimizer.step() for one parameter tensor from a caller-computed
+ * gradient (engine/optimizer/optim.py:34-71; torch.optim single-tensor recurrences):
+ * the same update kernel the fused step applies.  v may be NULL for SGD. */
+int  umlh_optimizer_step(int32_t optimizer, float* param, const float* grad, float* m, float* v, int64_t n,
+                         double lr, int64_t step, double beta1, double beta2, double eps, double momentum,
+                         double weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,107 @@
+"""GPU: the reference-shaped train()/validate() on the fused HIP step replays the
+reference's own finetune.train() runs (golden fixtures) under identical seeds:
+same batches, per-step losses, eval accuracies, early-stop iteration, best weights,
+final top-1 within +-0.1 pp (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("tag", ["lin_zs", "mlp_lt", "lin_imgonly"])
+def test_train_replays_reference_run(tag):
+    import finetune as ft
+    from engine.datasets.utils import FeatureLoader, FeatureTable, TextTensorDataset
+    from engine.models.head import UML
+    from engine.optimizer.optim import build_optimizer
+    from engine.optimizer.scheduler import build_lr_scheduler
+    from engine.tools.utils import set_random_seed
+    import umlh
+
+    g = load_golden("train_" + tag)
+    (d_img, text_indim, C, B, max_iters, eval_freq, patience, lr, wd, alpha, learnable, zeroshot, seed) = g["cfg"]
+    d_img, text_indim, C, B, max_iters, eval_freq, patience, seed = map(
+        int, (d_img, text_indim, C, B, max_iters, eval_freq, patience, seed))
+    modality = str(g["modality"])
+    T = torch.as_tensor
+    set_random_seed(seed)                                                    # finetune.py:452-454
+    text_ds = TextTensorDataset(T(g["x_txt"]), T(g["y_txt"]), torch.zeros(len(g["y_txt"]), dtype=torch.long))
+    model = UML(d_img, text_indim, C, bias=False, learnable_temp=bool(learnable))
+    np.testing.assert_array_equal(model.head.weight.detach().numpy(), g["w_head_init"])
+    model.to(DEV)
+    if zeroshot:
+        model.zero_shot_init(text_ds)
+    optimizer = build_optimizer(model.parameters(), str(g["optim"]), float(lr), float(wd))
+    scheduler = build_lr_scheduler(optimizer, "cosine", 50, max_iters, warmup_type="linear", warmup_lr=1e-5)
+    image_loader = FeatureLoader(FeatureTable(T(g["x_img"]), T(g["y_img"]), DEV), B, shuffle=True, kind="image")
+    text_loader = FeatureLoader(FeatureTable(text_ds.input_tensor, text_ds.label_tensor, DEV), B, shuffle=True, kind="text")
+    if modality == "image":
+        text_loader = None
+    val_loader = FeatureLoader(FeatureTable(T(g["x_val"]), T(g["y_val"]), DEV), B, shuffle=False)
+    test_loader = FeatureLoader(FeatureTable(T(g["x_test"]), T(g["y_test"]), DEV), B, shuffle=False)
+    out = ft.train(model, image_loader, text_loader, val_loader, test_loader, optimizer, scheduler, device=DEV,
+                   max_iters=max_iters, alpha=float(alpha), eval_freq=eval_freq, patience=patience)
+    test_loss, test_acc = ft.validate(model, test_loader, device=DEV)
+
+    n = int(g["n_steps"])
+    sc = out["train_scalars"].numpy()
+    assert sc.shape[0] == n                                                  # same early-stop step
+    ce = g["train_ce"]
+    if modality == "image":
+        np.testing.assert_allclose(sc[:, umlh.S_LOSS_IMG], ce, atol=1e-4)
+    else:
+        np.testing.assert_allclose(sc[:, umlh.S_LOSS_IMG], ce[0::2], atol=1e-4)
+        np.testing.assert_allclose(sc[:, umlh.S_LOSS_TXT], ce[1::2], atol=1e-4)
+    assert out["iter"] == int(g["best_iter"])
+    assert abs(out["val_acc"] - float(g["best_val_acc"])) < 1e-6
+    assert abs(out["val_loss"] - float(g["best_val_loss"])) < 1e-4
+    np.testing.assert_allclose(out["model"]["head.weight"].numpy(), g["w_head_best"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(model.head.weight.detach().cpu().numpy(), g["w_head_best"], atol=1e-5, rtol=1e-4)
+    if "w_proj_best" in g.files:
+        np.testing.assert_allclose(out["model"]["img_proj.weight"].numpy(), g["w_proj_best"], atol=1e-5, rtol=1e-4)
+    if bool(learnable):
+        assert abs(float(out["model"]["img_scale"]) - float(g["img_scale_best"])) < 1e-5
+        assert abs(float(out["model"]["txt_scale"]) - float(g["txt_scale_best"])) < 1e-5
+    assert abs(test_acc - float(g["test_acc"])) <= 1e-3                      # +-0.1 pp
+    assert abs(test_loss - float(g["test_loss"])) < 1e-4
+    assert set(out) >= {"iter", "val_acc", "model", "val_classwise", "val_loss", "model_records"}
+
+
+def test_model_forward_and_optimizer_step_unfused():
+    """model(images, text) returns the reference's logits pair; optimizer.step() applies the
+    HIP update kernel from .grad (the unfused surface of the drop-in)."""
+    from engine.models.head import UML, UMLClip
+    from engine.optimizer.optim import build_optimizer
+    from oracle import uml_oracle as O
+    g = load_golden("step_mlp_d48_t64_c10")
+    m = UML(48, 64, 10, learnable_temp=True).to(DEV)
+    with torch.no_grad():
+        m.head.weight.copy_(torch.as_tensor(g["w_head"]))
+        m.img_proj.weight.copy_(torch.as_tensor(g["w_proj"]))
+        m.img_scale.fill_(float(g["scale_img"]))
+        m.txt_scale.fill_(float(g["scale_txt"]))
+    zi, zt = m(torch.as_tensor(g["x_img"]).to(DEV), torch.as_tensor(g["x_txt"]).to(DEV))
+    np.testing.assert_allclose(zi.cpu().numpy(), g["img_logits"], atol=1e-4)
+    np.testing.assert_allclose(zt.cpu().numpy(), g["txt_logits"], atol=1e-4)
+    zi2, none = m(torch.as_tensor(g["x_img"]).to(DEV))
+    assert none is None and torch.equal(zi, zi2)
+    f = m.extract_features(torch.as_tensor(g["x_img"]).to(DEV))
+    np.testing.assert_allclose(f.cpu().numpy(), g["x_img"] @ g["w_proj"].T, atol=1e-5)
+    # optimizer.step() from a caller-provided gradient
+    opt = build_optimizer([m.head.weight], "adamw", 1e-3, 0.01)
+    m.head.weight.grad = torch.as_tensor(g["g_head"]).to(DEV)
+    st = O.HeadState(g["w_head"].copy())
+    O.optimizer_step(st, {"w_head": g["g_head"]}, O.OptState("adamw", 0.01), 1e-3)
+    opt.step()
+    np.testing.assert_allclose(m.head.weight.detach().cpu().numpy(), st.w_head, atol=1e-7, rtol=1e-6)
+    opt.zero_grad()
+    assert m.head.weight.grad is None
+    c = UMLClip("ViT-B/16", 7).to(DEV)
+    x = torch.nn.functional.normalize(torch.randn(5, 512), dim=1).to(DEV)
+    z, _ = c(x)
+    ref = (x.cpu().numpy() @ c.head.weight.detach().cpu().numpy().T) * np.float32(np.exp(np.log(1 / 0.07)))
+    np.testing.assert_allclose(z.cpu().numpy(), ref, atol=1e-4)

@@ -1,0 +1,148 @@
+"""CPU tests of the reference-shaped host API (no GPU compute): scheduler values
+against the reference's golden LR traces, loader order against torch's own
+DataLoader under the same seed, TextTensorDataset reductions, factory errors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+class _FakeOpt:
+    def __init__(self, lr):
+        self.param_groups = [{"lr": lr, "initial_lr": lr}]
+
+
+@pytest.mark.parametrize("tag,kind,wtype", [("cos_lin", "cosine", "linear"), ("cos_const", "cosine", "constant"),
+                                            ("lin_lin", "linear", "linear"), ("cos_nowarm", "cosine", None)])
+def test_scheduler_matches_reference_traces(tag, kind, wtype):
+    from engine.optimizer.scheduler import build_lr_scheduler
+    g = load_golden("lr_traces")
+    lr, warm, max_iter, wlr = g[tag + "_cfg"]
+    opt = _FakeOpt(float(lr))
+    s = build_lr_scheduler(opt, kind, int(warm), int(max_iter), warmup_type=wtype, warmup_lr=None if wlr < 0 else float(wlr))
+    ref = g[tag]
+    got = []
+    for _ in range(len(ref)):
+        got.append(opt.param_groups[0]["lr"])
+        assert s.get_last_lr()[0] == opt.param_groups[0]["lr"]
+        s.step()
+    # closed form vs torch's recursive cosine: agree to fp64 round-off
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-16)
+    np.testing.assert_allclose(s.__class__(opt, kind, max_iter, int(warm), wtype, None if wlr < 0 else float(wlr)).lr_table(8, 0),
+                               ref[:8], rtol=1e-9, atol=1e-16)
+
+
+def test_scheduler_and_optimizer_argument_errors():
+    from engine.optimizer.optim import build_optimizer
+    from engine.optimizer.scheduler import build_lr_scheduler
+    with pytest.raises(ValueError):
+        build_lr_scheduler(_FakeOpt(1e-3), "step", 0, 10)
+    with pytest.raises(ValueError):
+        build_lr_scheduler(_FakeOpt(1e-3), "cosine", 5, 10, warmup_type="exp", warmup_lr=1e-5)
+    with pytest.raises(AssertionError):
+        build_optimizer([torch.nn.Parameter(torch.zeros(2))], "lion", 1e-3, 0.0)
+    o = build_optimizer([torch.nn.Parameter(torch.zeros(2))], "adamw", 1e-3, 0.01)
+    assert o.param_groups[0]["lr"] == 1e-3 and o.param_groups[0]["weight_decay"] == 0.01 and o.step_count == 0
+
+
+def test_hyper_dict_grids():
+    from engine.optimizer.default import HYPER_DICT
+    g = HYPER_DICT["clip_linear"]
+    assert g["optim"] == "adamw" and g["lr"] == [0.001, 0.0001] and g["weight_decay"] == [0.0, 0.01, 0.001]
+    assert g["batch_size"] == [32] and g["max_iter"] == [12800] and g["warmup_iter"] == 50 and g["patience"] == [5]
+    assert HYPER_DICT["linear"]["learnable_temp"] == [True] and HYPER_DICT["linear"]["batch_size"] == [8, 32]
+    assert set(HYPER_DICT) == {"full_ds_full_model_finetune", "clip_linear", "linear", "audio"}
+
+
+class _DictDS(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {"i": i}
+
+
+def test_feature_loader_order_equals_torch_dataloader_under_same_seed():
+    """Two interleaved loaders cycled with fetch_next + an unshuffled loader iterated in
+    between (validate) -- the global-RNG protocol of finetune.train."""
+    from engine.datasets.utils import FeatureLoader, FeatureTable
+    from finetune import fetch_next
+    n_a, n_b, bs = 50, 23, 8
+
+    def run(make_a, make_b, make_v, get):
+        torch.manual_seed(1234)
+        la, lb, lv = make_a(), make_b(), make_v()
+        ia, ib = iter(la) if not hasattr(la, "iter_index") else la.iter_index(), \
+            iter(lb) if not hasattr(lb, "iter_index") else lb.iter_index()
+        seq = []
+        for step in range(25):
+            if hasattr(la, "iter_index"):
+                try:
+                    a = next(ia)
+                except StopIteration:
+                    ia = la.iter_index(); a = next(ia)
+                try:
+                    b = next(ib)
+                except StopIteration:
+                    ib = lb.iter_index(); b = next(ib)
+            else:
+                a, ia = fetch_next(la, ia)
+                b, ib = fetch_next(lb, ib)
+            seq.append((get(a), get(b)))
+            if step % 10 == 0:
+                for _ in (lv.iter_index() if hasattr(lv, "iter_index") else lv):
+                    pass
+        return seq
+
+    from torch.utils.data import DataLoader
+    ref = run(lambda: DataLoader(_DictDS(n_a), batch_size=bs, shuffle=True), lambda: DataLoader(_DictDS(n_b), batch_size=bs, shuffle=True),
+              lambda: DataLoader(_DictDS(9), batch_size=4, shuffle=False), lambda b: b["i"].tolist())
+    tab = lambda n: FeatureTable(torch.zeros(n, 2), torch.zeros(n, dtype=torch.long), "cpu")
+    got = run(lambda: FeatureLoader(tab(n_a), bs, shuffle=True), lambda: FeatureLoader(tab(n_b), bs, shuffle=True),
+              lambda: FeatureLoader(tab(9), 4, shuffle=False), lambda b: b.tolist())
+    assert got == ref
+
+
+def test_text_tensor_dataset_reductions_golden():
+    from engine.datasets.utils import TextTensorDataset
+    g = load_golden("text_side")
+    f, l, e = torch.as_tensor(g["feats"]), torch.as_tensor(g["labels"]), torch.as_tensor(g["eot"])
+    avg = TextTensorDataset(f, l, e, n_shots="average")
+    np.testing.assert_allclose(avg.input_tensor.numpy(), g["avg_feats"], atol=1e-6)
+    np.testing.assert_array_equal(avg.label_tensor.numpy(), g["avg_labels"])
+    np.testing.assert_array_equal(avg.eot_indices.numpy(), g["avg_eot"])
+    torch.manual_seed(int(g["shot_seed"]))
+    shot = TextTensorDataset(f, l, e, n_shots=3)
+    np.testing.assert_array_equal(shot.input_tensor.numpy(), g["shot_feats"])
+    np.testing.assert_array_equal(shot.label_tensor.numpy(), g["shot_labels"])
+    np.testing.assert_array_equal(shot.eot_indices.numpy(), g["shot_eot"])
+    assert len(shot) == len(g["shot_labels"]) and len(shot[0]) == 3
+    with pytest.raises(ValueError):
+        TextTensorDataset(f, l, e, n_shots=2.5)
+
+
+def test_model_surface_and_seed_parity_of_init():
+    """UML/UMLClip expose the reference attributes; nn.Linear init order consumes the
+    global RNG like the reference (w_head_init of the golden run)."""
+    from engine.models.head import UML, UMLClip
+    from engine.tools.utils import set_random_seed
+    g = load_golden("train_mlp_lt")
+    d_img, text_indim, C = int(g["cfg"][0]), int(g["cfg"][1]), int(g["cfg"][2])
+    set_random_seed(int(g["cfg"][12]))
+    m = UML(d_img, text_indim, C, bias=False, learnable_temp=True)
+    np.testing.assert_array_equal(m.head.weight.detach().numpy(), g["w_head_init"])
+    np.testing.assert_array_equal(m.img_proj.weight.detach().numpy(), g["w_proj_init"])
+    assert m.num_classes == C and m.shared_dim == text_indim and m.img_proj is not None
+    assert list(dict(m.named_parameters())) == ["img_scale", "txt_scale", "img_proj.weight", "head.weight"] or \
+        set(dict(m.named_parameters())) == {"img_proj.weight", "head.weight", "img_scale", "txt_scale"}
+    c = UMLClip("ViT-B/16", 10)
+    assert c.shared_dim == 512 and c.img_proj is None and abs(float(c._scales[0]) - 1 / 0.07) < 1e-3
+    assert hasattr(c, "extract_features") and hasattr(m, "extract_raw_features") and hasattr(m, "zero_shot_init")
+    with pytest.raises(NotImplementedError):
+        UML(8, 0, 3, bias=True)
+    with pytest.raises(ValueError):
+        UML("vit_base_patch16_224", 0, 3)

@@ -228,6 +228,37 @@ int umlh_logits(umlh_handle_t h, const umlh_batch_t* b, int modality, float* out
     return UMLH_OK;
 }
 
+int umlh_project(umlh_handle_t h, const umlh_batch_t* b, float* out, void* stream) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_project: handle not bound");
+    if (!b || !out) return fail(UMLH_E_INVALID, "umlh_project: null argument");
+    if (!h->cfg.has_proj) return fail(UMLH_E_INVALID, "umlh_project: head has no img_proj");
+    int rc = check_batch(h, b, h->L.rcap_img, "umlh_project");
+    if (rc) return rc;
+    if (b->rows == 0) return UMLH_OK;
+    HIPCHK(launch_proj_forward(h, b, out, (hipStream_t)stream), "proj forward");
+    return UMLH_OK;
+}
+
+int umlh_optimizer_step(int32_t optimizer, float* param, const float* grad, float* m, float* v, int64_t n, double lr,
+                        int64_t step, double beta1, double beta2, double eps, double momentum, double weight_decay,
+                        void* stream) {
+    if (optimizer < UMLH_OPT_SGD || optimizer > UMLH_OPT_ADAMW)
+        return fail(UMLH_E_INVALID, "umlh_optimizer_step: unknown optimizer %d", optimizer);
+    if (!param || !grad || !m || (optimizer != UMLH_OPT_SGD && !v) || n < 0)
+        return fail(UMLH_E_INVALID, "umlh_optimizer_step: null buffer");
+    umlh_config_t c;
+    memset(&c, 0, sizeof(c));
+    c.optimizer = optimizer; c.beta1 = beta1; c.beta2 = beta2; c.eps = eps; c.momentum = momentum;
+    c.weight_decay = weight_decay;
+    umlh_hyper_t hy;
+    memset(&hy, 0, sizeof(hy));
+    hy.lr = lr; hy.step = step;
+    OptArgs o = make_opt(c, hy);
+    HIPCHK(umlh_launch_reduce_update(1, grad, 1, n, n, nullptr, param, m, v, &o, (hipStream_t)stream),
+           "optimizer step");
+    return UMLH_OK;
+}
+
 // Everything of a step up to (not including) the parameter update.
 static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
                             const umlh_hyper_t* hy, bool want_grad, hipStream_t st, int* n_slabs_head,

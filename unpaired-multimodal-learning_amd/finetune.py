@@ -1,0 +1,220 @@
+"""The UML supervised fine-tune loop on the fused HIP step.
+
+Mirror of the hot path of the reference's ``vision_language/finetune.py``:
+``fetch_next`` (:33-39), ``train`` (:120-288), ``validate`` (:291-315) -- same
+signatures, step order, loss weighting, evaluation cadence, early stopping,
+best-snapshot restore and returned dict -- with the per-step body
+(:180-195: forward, 2x cross-entropy, backward, optimizer.step) executed by
+``HeadEngine.train_step`` (one launch sequence, logits never leave registers,
+no host synchronisation inside a step).
+
+What the reference does per step only for logging (two extra backward passes for
+per-modality gradient statistics :190-191,200-206, a second backbone forward :183)
+is not on this path.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+import umlh
+from engine.datasets.utils import FeatureLoader, FeatureTable, TextTensorDataset  # noqa: F401
+from engine.models.head import UML, UMLClip  # noqa: F401
+from engine.optimizer.default import HYPER_DICT  # noqa: F401
+from engine.optimizer.optim import build_optimizer  # noqa: F401
+from engine.optimizer.scheduler import build_lr_scheduler  # noqa: F401
+
+EVAL_FREQ = 100   # evaluate on the val set every 100 iterations (early stopping)
+
+
+def fetch_next(loader, loader_iter):
+    """next(loader_iter), restarting the loader when it is exhausted: each modality
+    cycles independently of the other (that is the 'unpaired' pairing)."""
+    try:
+        batch = next(loader_iter)
+    except StopIteration:
+        loader_iter = iter(loader)
+        batch = next(loader_iter)
+    return batch, loader_iter
+
+
+class _RowSource:
+    """Adapts a loader to the fused step.  A ``FeatureLoader`` is consumed as index
+    vectors into its device-resident table; any other iterable (e.g. a torch
+    DataLoader yielding the reference's dict / tuple batches) is consumed as dense
+    batches moved to ``device``."""
+
+    def __init__(self, loader, device, kind):
+        self.loader, self.device, self.kind = loader, device, kind
+        self.indexed = hasattr(loader, "iter_index")
+        self._make_iter = loader.iter_index if self.indexed else loader.__iter__
+        self.it = self._make_iter()
+
+    @property
+    def capacity(self):
+        return int(getattr(self.loader, "batch_size", None) or 4096)
+
+    def next(self) -> umlh.RowBatch:
+        batch, self.it = fetch_next(_Reiter(self._make_iter), self.it)
+        if self.indexed:
+            t = self.loader.table
+            return umlh.RowBatch(t.features, t.labels, batch)
+        if self.kind == "image":
+            x, y = batch["img"], batch["label"]
+        else:
+            x, y = batch[0], batch[1]
+        return umlh.RowBatch(x.to(self.device, torch.float32).contiguous(), y.to(self.device, torch.int64).contiguous())
+
+
+class _Reiter:
+    def __init__(self, make):
+        self.make = make
+
+    def __iter__(self):
+        return self.make()
+
+
+def _state_dict_cpu(model):
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, scheduler, device="cuda",
+          max_iters=1000, alpha=1.0, eval_freq=EVAL_FREQ, patience=5, capture_features_during_training=False,
+          features_pth="./", args=None, logger=None, precision="fp32"):
+    out = {"iter": None, "val_acc": None, "model": None, "val_classwise": None, "val_loss": None,
+           "model_records": []}
+    model.train()
+    assert image_loader is not None or text_loader is not None, "At least one of the loaders should be provided"
+    if capture_features_during_training:
+        print("=> capture_features_during_training is a logging-only diagnostic; not on the fused path (ignored)")
+    dev = model.head.weight.device
+    img_src = _RowSource(image_loader, dev, "image") if image_loader is not None else None
+    txt_src = _RowSource(text_loader, dev, "text") if text_loader is not None else None
+    engine = model.fused_engine(optimizer, max_rows_img=img_src.capacity if img_src else 32,
+                                max_rows_txt=txt_src.capacity if txt_src else 32, precision=precision)
+    scalars = torch.zeros(max_iters, umlh.N_SCALARS, dtype=torch.float32, device=dev)
+    no_improve = 0
+    img_alpha = 1.0
+    last_i = -1
+    for i in range(max_iters):
+        img_rows = img_src.next() if img_src is not None else None
+        txt_rows = txt_src.next() if txt_src is not None else None
+        engine.train_step(img_rows, txt_rows, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1,
+                          alpha=alpha, img_alpha=img_alpha, scalars_out=scalars[i])
+        optimizer.step_count += 1
+        scheduler.step()
+        last_i = i
+        if logger is not None:
+            s = scalars[i].cpu()                      # host sync: only when a logger asks for per-step values
+            logger.log({"train/image_loss": float(s[umlh.S_LOSS_IMG]), "train/text_loss": float(s[umlh.S_LOSS_TXT]),
+                        "train/image_acc": float(s[umlh.S_ACC_IMG]), "train/text_acc": float(s[umlh.S_ACC_TXT]),
+                        "train/lr": scheduler.get_last_lr()[0]})
+        if i % eval_freq == 0:
+            state_dict_cpu = _state_dict_cpu(model)
+            val_loss, val_acc = validate(model, val_loader, device=device)
+            testlog = ""
+            if test_loader is not None:
+                _, test_acc = validate(model, test_loader, device=device)
+                testlog = f" | Test Acc: {test_acc:.4f}"
+            if out["val_acc"] is None or val_acc > out["val_acc"]:
+                out.update(iter=i, val_acc=val_acc, val_loss=val_loss, model=state_dict_cpu)
+                no_improve = 0
+            else:
+                no_improve += 1
+            if logger is not None:
+                logger.log({"val/val_loss": val_loss, "val/val_acc": val_acc, "iter": i})
+            s = scalars[i].cpu()
+            print(f"Iter {i} | Img Loss: {s[umlh.S_LOSS_IMG]:.4f} | Text Loss: {s[umlh.S_LOSS_TXT]:.4f} | "
+                  f"Img Acc: {s[umlh.S_ACC_IMG]:.4f} | Text Acc: {s[umlh.S_ACC_TXT]:.4f} | Val Loss: {val_loss:.4f} | "
+                  f"Val Acc {val_acc:.4f}{testlog} | Count {no_improve}/{patience}")
+            if no_improve >= patience:
+                print(f"=> Early stopping at Iter {i}")
+                break
+    model.load_state_dict(out["model"])
+    val_loss, val_acc = validate(model, val_loader, device=device)
+    if logger is not None:
+        logger.log({"val/best_val_loss": val_loss, "val/best_val_acc": val_acc, "iter": out["iter"]})
+    print(f"=> Best Val Loss {val_loss:.4f}, Val Acc {val_acc:.4f} at Iter {out['iter']}")
+    out["train_scalars"] = scalars[:last_i + 1].cpu()   # per-step losses / accuracies (extension)
+    return out
+
+
+def validate(model, val_loader, device="cuda"):
+    """val_acc = mean over all rows of (argmax == label); val_loss = mean over batches
+    of the per-batch mean CE (not sample weighted).  One host read at the end."""
+    dev = model.head.weight.device
+    model.eval()
+    src_indexed = hasattr(val_loader, "iter_index")
+    rows, slots = [], []
+    it = val_loader.iter_index() if src_indexed else iter(val_loader)
+    engine = None
+    for batch in it:
+        if src_indexed:
+            t = val_loader.table
+            rb = umlh.RowBatch(t.features, t.labels, batch)
+        else:
+            rb = umlh.RowBatch(batch["img"].to(dev, torch.float32).contiguous(),
+                               batch["label"].to(dev, torch.int64).contiguous())
+        n = rb.n_rows()
+        if engine is None or engine.cfg.max_rows_img < n:
+            engine = model._infer_engine(n)
+        slot = torch.zeros(umlh.N_SCALARS, dtype=torch.float32, device=dev)
+        engine.eval_batch(rb, slot)
+        rows.append(n)
+        slots.append(slot)
+    s = torch.stack(slots).cpu()
+    counts = torch.tensor(rows, dtype=torch.float32)
+    val_acc = (s[:, umlh.S_CORRECT].sum() / counts.sum()).item()
+    val_loss = (s[:, umlh.S_LOSS_SUM] / counts).mean().item()
+    model.train()
+    return val_loss, val_acc
+
+
+def hparam_str(optim, lr, wd, batch_size, iters, dropout, learnable_temp):
+    base = f"optim_{optim}-lr_{lr}-wd_{wd}-bs_{batch_size}-iters_{iters}"
+    if dropout is not None:
+        base += f"-dropout_{dropout}"
+    if learnable_temp is True:
+        base += "-learnable_temp"
+    return base
+
+
+def setup_feature_run(img_train, img_val, img_test, text_ds, hparams, *, num_classes, modality="crossmodal",
+                      alpha=1.0, classifier_init="zeroshot", use_clip=False, clip_logit=4.60517, text_indim=None,
+                      device="cuda:0", eval_test=True, precision="fp32", eval_freq=EVAL_FREQ):
+    """``setup()`` (finetune.py:323-404) for pre-extracted features: builds the model,
+    optimizer, scheduler and the four loaders with the reference's wiring, trains, tests.
+
+    img_* are (features [N,d], labels [N]) pairs; text_ds a TextTensorDataset."""
+    d_img = img_train[0].shape[1]
+    d_txt = text_ds.input_tensor.shape[1]
+    if use_clip:
+        model = UMLClip(d_img, num_classes, logit_scale_init=clip_logit, bias=False,
+                        learnable_temp=hparams["learnable_temp"])
+    else:
+        tin = (d_txt if text_indim is None else text_indim) if modality == "crossmodal" else (text_indim or 0)
+        model = UML(d_img, tin, num_classes, bias=False, learnable_temp=hparams["learnable_temp"])
+    model.to(device)
+    if classifier_init == "zeroshot" and (modality == "crossmodal" or model.shared_dim == d_txt):
+        model.zero_shot_init(text_ds)
+    optimizer = build_optimizer(model.parameters(), hparams["optim"], hparams["lr"], hparams["weight_decay"])
+    scheduler = build_lr_scheduler(optimizer, hparams["lr_scheduler"], hparams["warmup_iter"], hparams["max_iter"],
+                                   warmup_type=hparams["warmup_type"], warmup_lr=hparams["warmup_min_lr"])
+    bs = hparams["batch_size"]
+    image_loader = FeatureLoader(FeatureTable(*img_train, device), bs, shuffle=True, kind="image")
+    text_loader = FeatureLoader(FeatureTable(text_ds.input_tensor, text_ds.label_tensor, device, text_ds.eot_indices),
+                                bs, shuffle=True, kind="text")
+    if modality == "image":
+        text_loader = None
+    elif modality == "text":
+        image_loader = None
+    val_loader = FeatureLoader(FeatureTable(*img_val, device), bs, shuffle=False, kind="image")
+    test_loader = FeatureLoader(FeatureTable(*img_test, device), bs, shuffle=False, kind="image")
+    result = train(model, image_loader, text_loader, val_loader, test_loader if eval_test else None, optimizer,
+                   scheduler, device=device, max_iters=hparams["max_iter"], alpha=alpha, eval_freq=eval_freq,
+                   patience=hparams["patience"], precision=precision)
+    test_loss, test_acc = validate(model, test_loader, device=device)
+    return {"test_acc": test_acc, "test_loss": test_loss, "val_acc": result["val_acc"], "model": result["model"],
+            "iter": result["iter"], "train_scalars": result["train_scalars"]}

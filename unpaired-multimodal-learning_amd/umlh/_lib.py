@@ -21,7 +21,7 @@ N_SCALARS = 8
 SOURCES = ["umlh_kernels_f32.hip", "umlh_api.cpp"]
 EXPORTS = ["umlh_last_error", "umlh_version", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
-           "umlh_apply_update", "umlh_eval_batch"]
+           "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step"]
 
 
 class UmlhError(RuntimeError):
@@ -103,6 +103,9 @@ def load_library():
     lib.umlh_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.umlh_apply_update.argtypes = [vp, C.POINTER(Hyper), vp, vp]
     lib.umlh_eval_batch.argtypes = [vp, C.POINTER(Batch), vp, vp]
+    lib.umlh_project.argtypes = [vp, C.POINTER(Batch), vp, vp]
+    lib.umlh_optimizer_step.argtypes = [i32, vp, vp, vp, vp, i64, C.c_double, i64, C.c_double, C.c_double,
+                                        C.c_double, C.c_double, C.c_double, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("umlh_last_error", "umlh_workspace_bytes"):

@@ -152,6 +152,14 @@ class HeadEngine:
             check(self.lib.umlh_logits(self.handle, C.byref(b), modality, _ptr(out), self._stream()), "umlh_logits")
         return out
 
+    def project(self, batch: RowBatch) -> torch.Tensor:
+        """img_proj(feats) -> [rows, d_shared]  (engine/models/head.py:87-90)."""
+        b = self._batch(batch, self.d_img)
+        out = torch.empty(batch.n_rows(), self.d_shared, dtype=torch.float32, device=self.device)
+        if b is not None:
+            check(self.lib.umlh_project(self.handle, C.byref(b), _ptr(out), self._stream()), "umlh_project")
+        return out
+
     def train_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], lr: float, step: int,
                    alpha: float = 1.0, img_alpha: float = 1.0, scalars_out: Optional[torch.Tensor] = None):
         bi, bt = self._batch(img, self.d_img), self._batch(txt, self.d_shared)
@@ -187,3 +195,17 @@ class HeadEngine:
         so = scalars_out if scalars_out is not None else self._scalars
         check(self.lib.umlh_eval_batch(self.handle, self._ref(b), _ptr(so), self._stream()), "umlh_eval_batch")
         return so
+
+
+def optimizer_step(name: str, param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: Optional[torch.Tensor], *,
+                   lr: float, step: int, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                   momentum: float = 0.9) -> None:
+    """Standalone ``optimizer.step()`` on one fp32 tensor through ``umlh_optimizer_step``."""
+    lib = _lib.load_library()
+    for t in (param, grad, m) + ((v,) if v is not None else ()):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != "cuda":
+            raise UmlhError("optimizer_step: contiguous fp32 GPU tensors required")
+    st = C.c_void_p(torch.cuda.current_stream(param.device).cuda_stream)
+    check(lib.umlh_optimizer_step(OPT_IDS[name], _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(),
+                                  float(lr), int(step), float(betas[0]), float(betas[1]), float(eps), float(momentum),
+                                  float(weight_decay), st), "umlh_optimizer_step")
