@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the UML head fine-tune hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: 4096 image-feature rows + 4096
+text-feature rows PER GPU through the shared linear head (fused GEMM + scale +
+softmax-CE forward, dW, AdamW), workload = BASELINE config 2 (ImageNet-1k, CLIP ViT-B/16
+features d=512, C=1000, unpaired CUPL text).  Inputs are synthetic, resident in HBM
+before the timed region.  N>1: plain data parallel, one RCCL all-reduce of the head
+gradient per step, weak scaling.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "unpaired-multimodal-learning_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+METRIC = "samples/sec (img+text feats) UML head fine-tune, batch 4096, 1/2/4/8 GPU"
+N_IMG, N_TXT, D, C, BATCH = 1_281_167, 29_940, 512, 1000, 4096
+PEAK = {"fp32": 157.3, "bf16": 2500.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+
+
+def synth_rows(n, d, c, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(n, d, generator=g, device=device, dtype=torch.float32)
+    x = torch.nn.functional.normalize(x, dim=1)
+    y = torch.randint(0, c, (n,), generator=g, device=device, dtype=torch.int64)
+    return x, y
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", default=os.environ.get("UMLH_PRECISION", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import umlh
+    from engine.datasets.utils import FeatureLoader, FeatureTable
+    from engine.models.head import UMLClip
+    from engine.optimizer.optim import build_optimizer
+    from engine.optimizer.scheduler import build_lr_scheduler
+    from engine.tools.utils import set_random_seed
+    from finetune import _RowSource
+
+    # ---- synthetic, HBM-resident workload (image rows sharded over ranks, text replicated) ----
+    set_random_seed(0)
+    n_img_local = (N_IMG + world - 1) // world
+    x_img, y_img = synth_rows(n_img_local, D, C, 100 + rank, dev)
+    x_txt, y_txt = synth_rows(N_TXT, D, C, 7, dev)
+    model = UMLClip(D, C, logit_scale_init=4.60517).to(dev)            # s = 100 (config/__init__.py:209-216)
+    model.zero_shot_init(FeatureTableAsText(x_txt, y_txt))
+    optimizer = build_optimizer(model.parameters(), "adamw", 1e-3, 0.01)
+    scheduler = build_lr_scheduler(optimizer, "cosine", 50, 12800, warmup_type="linear", warmup_lr=1e-5)
+    torch.manual_seed(1234 + rank)                                       # per-rank shuffles
+    img_src = _RowSource(FeatureLoader(FeatureTable(x_img, y_img, dev), BATCH, shuffle=True, kind="image"), dev, "image")
+    txt_src = _RowSource(FeatureLoader(FeatureTable(x_txt, y_txt, dev), BATCH, shuffle=True, kind="text"), dev, "text")
+    engine = model.fused_engine(optimizer, BATCH, BATCH, precision=args.precision)
+    stepper = umlh.DataParallelStepper(engine)
+    stepper.broadcast_parameters([model.head.weight.data])
+    scal = torch.zeros(args.warmup + args.steps + 64, umlh.N_SCALARS, device=dev)
+
+    def one_step(k):
+        bi, bt = img_src.next(), txt_src.next()
+        stepper.step(bi, bt, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1, alpha=1.0,
+                     scalars_out=scal[k])
+        optimizer.step_count += 1
+        scheduler.step()
+        return bi.n_rows() + bt.n_rows()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        one_step(k)
+    fence()
+    t0 = time.perf_counter()
+    rows = 0
+    for k in range(args.steps):
+        rows += one_step(args.warmup + k)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        r = torch.tensor([rows], device=dev, dtype=torch.float64)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rows = int(r.item())
+    value = rows / dt
+
+    # ---- roofline leg: per-kernel device time from HIP events on the step's stream ----
+    engine.profile(True)
+    acc, nprof = {}, 30
+    for k in range(nprof):
+        one_step(args.warmup + args.steps + k)
+        for name, ms in engine.profile_read().items():
+            acc[name] = acc.get(name, 0.0) + ms / nprof
+    engine.profile(False)
+    flops = {"fwd_ce": 2.0 * 2 * BATCH * C * D, "dw_head": 2.0 * 2 * BATCH * C * D}   # per launch, algorithmic
+    dom = max(("fwd_ce", "dw_head"), key=lambda n: acc[n])
+    achieved = flops[dom] / (acc[dom] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[args.precision],
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.precision], 4), "traffic": None,
+                "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
+                "step_frac_of_mfma_roof": round((sum(flops.values()) / (PEAK[args.precision] * 1e12)) / (dt / args.steps), 4)}
+    final = scal[args.warmup + args.steps - 1].cpu().tolist()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_cpu_loop as cpu_loop
+        n_sub = 32768
+        xi, yi = x_img[:n_sub].cpu(), y_img[:n_sub].cpu()
+        xt, yt = x_txt.cpu(), y_txt.cpu()
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        # a 1-GPU box's CPU share is 16 cores; more torch threads than that only oversubscribes
+        threads = min(cores, int(os.environ.get("UMLH_CPU_THREADS", 16)))
+        ncpu = int(os.environ.get("UMLH_CPU_STEPS", 12))
+        v, secs, n = cpu_loop.reference_shaped_steps(xi, yi, xt, yt, C, BATCH, steps=ncpu, warmup=2, threads=threads)
+        vb, _, _ = cpu_loop.bare_math_steps(xi, yi, xt, yt, C, BATCH, steps=ncpu, warmup=2, threads=threads)
+        cpu = {"value": round(v, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+               "sample": f"{ncpu} timed steps (+2 warm-up) of 4096+4096 rows on a {n_sub}-row image subset, "
+                         f"reference-shaped torch-CPU loop (DataLoader collate, 3 backward passes, per-step scalars)",
+               "seconds": round(secs, 2), "bare_math_value": round(vb, 1), "host_cores_visible": cores}
+
+    if rank == 0:
+        out = {"metric": METRIC, "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
+               "data": "synthetic",
+               "config": {"workload": "cfg2 ImageNet-1k CLIP-ViT-B/16 features (d=512) + unpaired CUPL text, linear head "
+                                      "C=1000, 4096 img + 4096 txt rows/step/GPU, scale 100, zero-shot init, AdamW "
+                                      "lr 1e-3 wd 0.01, warm-up 50 + cosine 12800",
+                          "n_img_rows": N_IMG, "n_txt_rows": N_TXT, "global_batch": 2 * BATCH * world,
+                          "parallelism": f"dp{world}", "precision_mode": args.precision},
+               "final_loss": {"img": round(final[0], 4), "txt": round(final[1], 4)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        if cpu:
+            out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+class FeatureTableAsText:
+    """Minimal text-dataset view (input_tensor / label_tensor) for zero_shot_init."""
+
+    def __init__(self, x, y):
+        self.input_tensor, self.label_tensor = x, y
+
+
+if __name__ == "__main__":
+    main()

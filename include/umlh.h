@@ -153,6 +153,15 @@ int  umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hyper, float* scalar
  * per-batch means (finetune.py:311-312). */
 int  umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* batch, float* scalars_out, void* stream);
 
+/* Per-phase device timing of umlh_train_step / umlh_grad_step with HIP events recorded
+ * on the step's stream (bench.py's roofline leg; rocprofv3 --kernel-trace must agree).
+ * Phases: 0 img_proj forward GEMM, 1 fused forward+CE, 2 dW_head GEMM, 3 img_proj
+ * backward GEMMs, 4 slab reduce + optimizer + scalars.  enable creates the events,
+ * read synchronises on the last one and returns milliseconds of the latest step. */
+#define UMLH_N_PHASES 5
+int  umlh_profile_enable(umlh_handle_t h, int enable);
+int  umlh_profile_read(umlh_handle_t h, float* ms_out /* host float[UMLH_N_PHASES] */);
+
 /* Standalone optimizer.step() for one parameter tensor from a caller-computed
  * gradient (engine/optimizer/optim.py:34-71; torch.optim single-tensor recurrences):
  * the same update kernel the fused step applies.  v may be NULL for SGD. */

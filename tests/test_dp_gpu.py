@@ -1,0 +1,81 @@
+"""GPU: two ranks sharing the one MI355X of the test box (gloo transport, HIP engine):
+umlh_grad_step -> all_reduce -> umlh_apply_update equals the single-process fused step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case():
+    rng = np.random.default_rng(3)
+    d, C, B = 64, 100, 96
+    xi = rng.standard_normal((B, d)).astype(np.float32)
+    xt = rng.standard_normal((B, d)).astype(np.float32)
+    xi /= np.linalg.norm(xi, axis=1, keepdims=True)
+    xt /= np.linalg.norm(xt, axis=1, keepdims=True)
+    w = rng.standard_normal((C, d)).astype(np.float32)
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    return d, C, B, xi, rng.integers(0, C, B), xt, rng.integers(0, C, B), w
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "unpaired-multimodal-learning_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import umlh
+        d, C, B, xi, yi, xt, yt, w = _case()
+        dev = "cuda:0"
+        e = umlh.HeadEngine(d, d, C, optimizer="adamw", weight_decay=0.01, max_rows_img=128, max_rows_txt=128, device=dev)
+        e.w_head.copy_(torch.from_numpy(w))
+        e.scales.fill_(50.0)
+        T = lambda a, t: torch.as_tensor(a).to(dev, t).contiguous()
+        idx = torch.arange(rank, B, world, device=dev)
+        st = umlh.DataParallelStepper(e)
+        scal = torch.zeros(umlh.N_SCALARS, device=dev)
+        for k in range(2):
+            st.step(umlh.RowBatch(T(xi, torch.float32), T(yi, torch.int64), idx),
+                    umlh.RowBatch(T(xt, torch.float32), T(yt, torch.int64), idx), lr=1e-3, step=k + 1, scalars_out=scal)
+        torch.cuda.synchronize()
+        q.put((rank, e.w_head.cpu().numpy(), scal.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_matches_single_rank():
+    import torch.multiprocessing as mp
+    import umlh
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d, C, B, xi, yi, xt, yt, w = _case()
+    dev = "cuda:0"
+    e = umlh.HeadEngine(d, d, C, optimizer="adamw", weight_decay=0.01, max_rows_img=128, max_rows_txt=128, device=dev)
+    e.w_head.copy_(torch.from_numpy(w))
+    e.scales.fill_(50.0)
+    T = lambda a, t: torch.as_tensor(a).to(dev, t).contiguous()
+    scal = torch.zeros(umlh.N_SCALARS, device=dev)
+    for k in range(2):
+        e.train_step(umlh.RowBatch(T(xi, torch.float32), T(yi, torch.int64)),
+                     umlh.RowBatch(T(xt, torch.float32), T(yt, torch.int64)), lr=1e-3, step=k + 1, scalars_out=scal)
+    ref = e.w_head.cpu().numpy()
+    for rank, wr, sc in res:
+        diff = np.abs(wr - ref)
+        assert (diff > 1e-6 + 1e-5 * np.abs(ref)).mean() < 1e-3 and diff.max() < 5e-3   # Adam sign flips at |g|~eps
+        np.testing.assert_allclose(sc[:4], scal.cpu().numpy()[:4], atol=1e-5)
+    np.testing.assert_array_equal(res[0][1], res[1][1])

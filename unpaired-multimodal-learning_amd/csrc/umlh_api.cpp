@@ -84,7 +84,13 @@ struct umlh_handle_s {
     int ctw, wc, ts;            // fwd_ce tile configuration
     // state carried from umlh_grad_step to umlh_apply_update
     int last_rows_img, last_rows_txt;
+    hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
+    bool profiling;
 };
+
+static inline void mark(umlh_handle_t h, int i, hipStream_t st) {
+    if (h->profiling) (void)hipEventRecord(h->ev[i], st);
+}
 
 const char* umlh_last_error(void) { return g_err; }
 int umlh_version(void) { return 1; }
@@ -113,12 +119,37 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->bound = false;
     h->ts = umlh_f32_fwd_config(cfg->num_classes, &h->ctw, &h->wc);
     h->last_rows_img = h->last_rows_txt = 0;
+    h->profiling = false;
     memset(&h->buf, 0, sizeof(h->buf));
     *out = h;
     return UMLH_OK;
 }
 
+int umlh_profile_enable(umlh_handle_t h, int enable) {
+    if (!h) return fail(UMLH_E_INVALID, "umlh_profile_enable: null handle");
+    if (enable && !h->profiling) {
+        for (int i = 0; i <= UMLH_N_PHASES; ++i)
+            if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(UMLH_E_HIP, "umlh_profile_enable: hipEventCreate failed");
+        h->profiling = true;
+    } else if (!enable && h->profiling) {
+        for (int i = 0; i <= UMLH_N_PHASES; ++i) (void)hipEventDestroy(h->ev[i]);
+        h->profiling = false;
+    }
+    return UMLH_OK;
+}
+
+int umlh_profile_read(umlh_handle_t h, float* ms_out) {
+    if (!h || !ms_out) return fail(UMLH_E_INVALID, "umlh_profile_read: null argument");
+    if (!h->profiling) return fail(UMLH_E_INVALID, "umlh_profile_read: profiling not enabled");
+    if (hipEventSynchronize(h->ev[UMLH_N_PHASES]) != hipSuccess) return fail(UMLH_E_HIP, "umlh_profile_read: sync failed");
+    for (int i = 0; i < UMLH_N_PHASES; ++i)
+        if (hipEventElapsedTime(&ms_out[i], h->ev[i], h->ev[i + 1]) != hipSuccess)
+            return fail(UMLH_E_HIP, "umlh_profile_read: elapsed failed (run a step first)");
+    return UMLH_OK;
+}
+
 int umlh_destroy(umlh_handle_t h) {
+    if (h && h->profiling) umlh_profile_enable(h, 0);
     delete h;
     return UMLH_OK;
 }
@@ -272,7 +303,9 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     float* H = ws(h, L.h);
     float* dzt = ws(h, L.dzt);
 
+    mark(h, 0, st);
     if (ri > 0 && c.has_proj) HIPCHK(launch_proj_forward(h, img, H, st), "proj forward");
+    mark(h, 1, st);
 
     FwdArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -297,6 +330,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     fa.dzt = want_grad ? dzt : nullptr; fa.ldz = L.ldz;
     fa.partials = ws(h, L.partials);
     HIPCHK(umlh_f32_launch_fwd(&fa, h->ctw, h->wc, nb0 + nb1, st), "fwd_ce");
+    mark(h, 2, st);
     if (!want_grad) return UMLH_OK;
 
     // dW_head[c][k] = sum_r dZ^T[c][r] F[r][k]  over image rows then text rows
@@ -320,6 +354,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         HIPCHK(umlh_f32_launch_gemm(&g, 0, 1, splits, st), "dW_head gemm");
         *n_slabs_head = splits;
     }
+    mark(h, 3, st);
     *n_slabs_proj = 0;
     if (c.has_proj && ri > 0) {
         // dH^T[n][r] = sum_c W_head[c][n] dZ^T[c][r]   (image columns only)
@@ -349,6 +384,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         HIPCHK(umlh_f32_launch_gemm(&p, 0, 1, splits, st), "dW_proj gemm");
         *n_slabs_proj = splits;
     }
+    mark(h, 4, st);
     return UMLH_OK;
 }
 
@@ -402,6 +438,7 @@ int umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t
     if (sp > 0)
         HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj, nullptr,
                                          h->buf.w_proj, h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
+    mark(h, 5, st);
     return UMLH_OK;
 }
 
@@ -428,6 +465,7 @@ int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t*
     }
     h->last_rows_img = img ? img->rows : 0;
     h->last_rows_txt = txt ? txt->rows : 0;
+    mark(h, 5, st);
     return UMLH_OK;
 }
 

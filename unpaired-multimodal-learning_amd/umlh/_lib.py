@@ -21,7 +21,8 @@ N_SCALARS = 8
 SOURCES = ["umlh_kernels_f32.hip", "umlh_api.cpp"]
 EXPORTS = ["umlh_last_error", "umlh_version", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
-           "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step"]
+           "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step",
+           "umlh_profile_enable", "umlh_profile_read"]
 
 
 class UmlhError(RuntimeError):
@@ -106,6 +107,8 @@ def load_library():
     lib.umlh_project.argtypes = [vp, C.POINTER(Batch), vp, vp]
     lib.umlh_optimizer_step.argtypes = [i32, vp, vp, vp, vp, i64, C.c_double, i64, C.c_double, C.c_double,
                                         C.c_double, C.c_double, C.c_double, vp]
+    lib.umlh_profile_enable.argtypes = [vp, C.c_int]
+    lib.umlh_profile_read.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("umlh_last_error", "umlh_workspace_bytes"):

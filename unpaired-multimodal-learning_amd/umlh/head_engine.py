@@ -190,6 +190,17 @@ class HeadEngine:
         check(self.lib.umlh_apply_update(self.handle, C.byref(hy), _ptr(so), self._stream()), "umlh_apply_update")
         return so
 
+    PHASES = ("proj_fwd", "fwd_ce", "dw_head", "proj_bwd", "reduce_update")
+
+    def profile(self, enable: bool = True) -> None:
+        check(self.lib.umlh_profile_enable(self.handle, int(enable)), "umlh_profile_enable")
+
+    def profile_read(self):
+        """Per-phase milliseconds of the latest step (HIP events on the step's stream)."""
+        ms = (C.c_float * len(self.PHASES))()
+        check(self.lib.umlh_profile_read(self.handle, ms), "umlh_profile_read")
+        return dict(zip(self.PHASES, [float(x) for x in ms]))
+
     def eval_batch(self, batch: RowBatch, scalars_out: Optional[torch.Tensor] = None):
         b = self._batch(batch, self.d_img)
         so = scalars_out if scalars_out is not None else self._scalars
