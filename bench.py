@@ -75,8 +75,8 @@ def main():
     optimizer = build_optimizer(model.parameters(), "adamw", 1e-3, 0.01)
     scheduler = build_lr_scheduler(optimizer, "cosine", 50, 12800, warmup_type="linear", warmup_lr=1e-5)
     torch.manual_seed(1234 + rank)                                       # per-rank shuffles
-    img_src = _RowSource(FeatureLoader(FeatureTable(x_img, y_img, dev), BATCH, shuffle=True, kind="image"), dev, "image")
-    txt_src = _RowSource(FeatureLoader(FeatureTable(x_txt, y_txt, dev), BATCH, shuffle=True, kind="text"), dev, "text")
+    img_src = _RowSource(FeatureLoader(FeatureTable(x_img, y_img, dev), BATCH, shuffle=True, kind="image"), dev, "image", args.precision)
+    txt_src = _RowSource(FeatureLoader(FeatureTable(x_txt, y_txt, dev), BATCH, shuffle=True, kind="text"), dev, "text", args.precision)
     engine = model.fused_engine(optimizer, BATCH, BATCH, precision=args.precision)
     stepper = umlh.DataParallelStepper(engine)
     stepper.broadcast_parameters([model.head.weight.data])

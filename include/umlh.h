@@ -81,6 +81,8 @@ typedef struct {
     const int64_t* index;       /* device [rows] row ids into feats/labels, NULL = 0..rows-1 */
     int32_t        rows;        /* rows processed by THIS rank in this step (0 = absent)   */
     int32_t        global_rows; /* denominator of the CE mean: rows summed over all ranks  */
+    const void*    feats_bf16;  /* device [table_rows, dim] bf16 copy of feats (umlh_to_bf16);
+                                   required by train/grad/eval calls in UMLH_PREC_BF16 mode  */
 } umlh_batch_t;
 
 /* Per-step scalars: lr = scheduler value used by this optimizer.step()
@@ -161,6 +163,10 @@ int  umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* batch, float* scalars_
 #define UMLH_N_PHASES 5
 int  umlh_profile_enable(umlh_handle_t h, int enable);
 int  umlh_profile_read(umlh_handle_t h, float* ms_out /* host float[UMLH_N_PHASES] */);
+
+/* fp32 -> bf16 (round-to-nearest-even) copy of n elements: builds the bf16 shadow of a
+ * device-resident feature table once, for UMLH_PREC_BF16 handles. */
+int  umlh_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
 
 /* Standalone optimizer.step() for one parameter tensor from a caller-computed
  * gradient (engine/optimizer/optim.py:34-71; torch.optim single-tensor recurrences):

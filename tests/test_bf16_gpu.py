@@ -1,0 +1,131 @@
+"""GPU: the bf16 throughput mode.  Operands are rounded to bf16 (8 significant bits), so
+it is checked (a) tightly against the oracle fed the SAME bf16-rounded operands (isolates
+kernel correctness from operand rounding), (b) loosely against the exact fp32 oracle,
+(c) on accuracy parity with the fp32 mode over a short training run."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import uml_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bf16_round(a):
+    return torch.as_tensor(a).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _case(rng, d, C, n_img, n_txt, scale):
+    xi = rng.standard_normal((n_img, d)).astype(np.float32)
+    xt = rng.standard_normal((n_txt, d)).astype(np.float32)
+    xi /= np.linalg.norm(xi, axis=1, keepdims=True)
+    xt /= np.linalg.norm(xt, axis=1, keepdims=True)
+    w = rng.standard_normal((C, d)).astype(np.float32)
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    return xi, rng.integers(0, C, n_img), xt, rng.integers(0, C, n_txt), w
+
+
+def _engine(w, scale, cap_i, cap_t, precision, optimizer="adamw", wd=0.01):
+    import umlh
+    C, d = w.shape
+    e = umlh.HeadEngine(d, d, C, optimizer=optimizer, weight_decay=wd, max_rows_img=cap_i, max_rows_txt=cap_t,
+                        precision=precision, device=DEV)
+    e.w_head.copy_(torch.from_numpy(w))
+    e.scales.fill_(scale)
+    return e
+
+
+def _rb(x, y, idx=None):
+    import umlh
+    T = lambda a, t: torch.as_tensor(np.ascontiguousarray(a)).to(DEV, t).contiguous()
+    return umlh.RowBatch(T(x, torch.float32), T(y, torch.int64), None if idx is None else T(idx, torch.int64))
+
+
+@pytest.mark.parametrize("d,C,bi,bt,scale,stw", [(64, 10, 70, 33, 30.0, 1), (128, 100, 50, 64, 100.0, 1),
+                                                 (512, 1000, 300, 257, 100.0, 1), (512, 1000, 300, 257, 100.0, 2),
+                                                 (96, 397, 40, 0, 50.0, 1), (256, 37, 0, 90, 20.0, 1)])
+def test_bf16_grad_step_vs_oracle_on_rounded_operands(d, C, bi, bt, scale, stw, monkeypatch):
+    import umlh
+    monkeypatch.setenv("UMLH_BF16_STW", str(stw))
+    rng = np.random.default_rng(d + C)
+    xi, yi, xt, yt, w = _case(rng, d, C, 400, 350, scale)
+    ii = rng.permutation(400)[:bi] if bi else None
+    ti = rng.permutation(350)[:bt] if bt else None
+    e = _engine(w, scale, 512, 512, "bf16")
+    flat = e.grad_step(_rb(xi, yi, ii) if bi else None, _rb(xt, yt, ti) if bt else None, alpha=0.7)
+    torch.cuda.synchronize()
+    f = flat.cpu().numpy()
+    gh, sc = f[:C * d].reshape(C, d), f[C * d + 2:]
+    st = O.HeadState(_bf16_round(w), None, scale, scale, False)
+    so = O.step_grads(st, _bf16_round(xi[ii]) if bi else None, yi[ii] if bi else None,
+                      _bf16_round(xt[ti]) if bt else None, yt[ti] if bt else None, 0.7)
+    if bi:
+        assert abs(sc[umlh.S_LOSS_IMG] - so.loss_img) < 2e-3 and abs(sc[umlh.S_ACC_IMG] - so.acc_img) < 1e-6 + 2.0 / bi
+    if bt:
+        assert abs(sc[umlh.S_LOSS_TXT] - so.loss_txt) < 2e-3 and abs(sc[umlh.S_ACC_TXT] - so.acc_txt) < 1e-6 + 2.0 / bt
+    # dZ is rounded to bf16 before the dW product: 2^-9 relative per element
+    s = np.abs(so.grads["w_head"]).max()
+    np.testing.assert_allclose(gh, so.grads["w_head"], atol=8e-3 * s, rtol=2e-2)
+    # exact-fp32 oracle, loose
+    ex = O.step_grads(O.HeadState(w, None, scale, scale, False), xi[ii] if bi else None, yi[ii] if bi else None,
+                      xt[ti] if bt else None, yt[ti] if bt else None, 0.7)
+    if bi:
+        assert abs(sc[umlh.S_LOSS_IMG] - ex.loss_img) < 5e-2
+    assert np.abs(gh - ex.grads["w_head"]).max() < 5e-2 * np.abs(ex.grads["w_head"]).max()
+
+
+def test_bf16_eval_batch():
+    import umlh
+    rng = np.random.default_rng(2)
+    xi, yi, _, _, w = _case(rng, 128, 100, 300, 10, 100.0)
+    e = _engine(w, 100.0, 512, 32, "bf16")
+    sc = e.eval_batch(_rb(xi, yi)).cpu().numpy()
+    st = O.HeadState(_bf16_round(w), None, 100.0, 100.0, False)
+    z, _ = O.forward(st, _bf16_round(xi), None)
+    assert abs(sc[umlh.S_LOSS_SUM] / 300 - O.cross_entropy_mean(z, yi)) < 2e-3
+    assert abs(sc[umlh.S_CORRECT] - O.top1_correct(z, yi).sum()) <= 2
+
+
+def test_bf16_requires_linear_head_and_k_multiple_of_32():
+    import umlh
+    with pytest.raises(umlh.UmlhError):
+        umlh.HeadEngine(48, 64, 10, has_proj=True, precision="bf16", device=DEV)
+    with pytest.raises(umlh.UmlhError):
+        umlh.HeadEngine(40, 40, 10, precision="bf16", device=DEV)
+
+
+def test_bf16_training_accuracy_parity_with_fp32():
+    """Same seed, same batches: 300 AdamW steps in bf16 mode vs fp32 mode; final top-1 on
+    20k held-out rows within +-0.25 pp (north_star target +-0.1 pp; printed)."""
+    import umlh
+    rng = np.random.default_rng(11)
+    d, C, n = 128, 100, 20000
+    proto = rng.standard_normal((C, d)).astype(np.float32)
+
+    def draw(m):
+        y = rng.integers(0, C, m)
+        x = proto[y] + 2.5 * rng.standard_normal((m, d)).astype(np.float32)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32), y
+    xi, yi = draw(n)
+    xt, yt = draw(3000)
+    xe, ye = draw(20000)
+    w0 = O.zero_shot_weights(xt, yt, C)
+    accs = {}
+    for prec in ("fp32", "bf16"):
+        e = _engine(w0.copy(), 30.0, 256, 256, prec)
+        bi_t, bt_t = _rb(xi, yi), _rb(xt, yt)
+        g = torch.Generator().manual_seed(5)
+        for k in range(300):
+            ii = torch.randint(0, n, (256,), generator=g).to(DEV)
+            ti = torch.randint(0, 3000, (256,), generator=g).to(DEV)
+            e.train_step(umlh.RowBatch(bi_t.feats, bi_t.labels, ii, feats_bf16=bi_t.feats_bf16),
+                         umlh.RowBatch(bt_t.feats, bt_t.labels, ti, feats_bf16=bt_t.feats_bf16), lr=2e-3, step=k + 1)
+            if prec == "bf16" and bi_t.feats_bf16 is None:
+                bi_t.feats_bf16, bt_t.feats_bf16 = umlh.to_bf16(bi_t.feats), umlh.to_bf16(bt_t.feats)
+        ev = _engine(e.w_head.cpu().numpy(), 30.0, 20000, 32, "fp32")
+        sc = ev.eval_batch(_rb(xe, ye)).cpu().numpy()
+        accs[prec] = sc[umlh.S_CORRECT] / 20000
+    print(f"top-1 fp32 {accs['fp32']:.4f}  bf16 {accs['bf16']:.4f}  diff {100 * (accs['bf16'] - accs['fp32']):+.3f} pp")
+    assert accs["fp32"] > 0.5
+    assert abs(accs["bf16"] - accs["fp32"]) <= 0.0025

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 
 #include "umlh_common.h"
@@ -19,6 +20,24 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
 int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream);
 int umlh_launch_zero_shot(const float* feats, const int64_t* labels, long long n, int d, int C, float* w,
                           hipStream_t stream);
+int umlh_launch_to_bf16(const float* src, void* dst, long long n, hipStream_t stream);
+int umlh_bf16_fwd_ts(int wc, int stw);
+}
+
+// argument blocks of the bf16 kernels (layout must match umlh_kernels_bf16.hip)
+typedef unsigned short u16;
+struct SegDescB {
+    const u16* feats; const int64_t* feat_index; const int64_t* labels; const int64_t* label_index;
+    const float* scale_ptr; int rows, ld, col0, blk0; float w_over_rows;
+};
+struct FwdArgsB { SegDescB seg[2]; const u16* W; int C, K; u16* dzt; int ldz; float* partials; };
+struct DwArgsB {
+    const u16* A; const u16* B; const int64_t* k_rows; int ldb; const u16* B2; const int64_t* k_rows2; int ldb2;
+    float* out; int M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2; long long slab_stride;
+};
+extern "C" {
+int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
+int umlh_bf16_launch_dw(const DwArgsB* g, int splits, hipStream_t stream);
 }
 
 static thread_local char g_err[512] = "";
@@ -34,7 +53,7 @@ static int fail(int code, const char* fmt, ...) {
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 struct Layout {                 // workspace partition, in floats from the base
-    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, total;
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, total;
     int rcap_img, rcap_txt, ldz;     // padded row capacities
     int scap_head, scap_proj;        // split-K slab capacities
     long long n_head, n_proj;        // parameter counts
@@ -54,7 +73,9 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     if (!c.has_proj && c.d_img != c.d_shared) return false;
     if (c.max_rows_img < 0 || c.max_rows_txt < 0 || c.max_rows_img + c.max_rows_txt < 1) return false;
     if (c.optimizer < UMLH_OPT_SGD || c.optimizer > UMLH_OPT_ADAMW) return false;
-    if (c.precision != UMLH_PREC_FP32) return false;
+    if (c.precision != UMLH_PREC_FP32 && c.precision != UMLH_PREC_BF16) return false;
+    // bf16 mode: linear head only (img_proj GEMMs run in fp32 mode), K a multiple of the 32-wide chunk
+    if (c.precision == UMLH_PREC_BF16 && (c.has_proj || c.d_shared % 32 != 0)) return false;
     L.rcap_img = (int)round_up(c.max_rows_img, 256);
     L.rcap_txt = (int)round_up(c.max_rows_txt, 256);
     L.ldz = L.rcap_img + L.rcap_txt;
@@ -72,6 +93,7 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     L.slabs_proj = take((long long)L.scap_proj * L.n_proj);
     L.partials = take((long long)L.max_blocks * 4);
     L.grads = take(L.n_head + L.n_proj + 2 + UMLH_N_SCALARS);
+    L.w16 = take(c.precision == UMLH_PREC_BF16 ? (L.n_head + 1) / 2 : 0);   // bf16 shadow of w_head
     L.total = off;
     return true;
 }
@@ -82,6 +104,7 @@ struct umlh_handle_s {
     Layout L;
     bool bound;
     int ctw, wc, ts;            // fwd_ce tile configuration
+    int stw;                    // bf16: 32-sample tiles per wave
     // state carried from umlh_grad_step to umlh_apply_update
     int last_rows_img, last_rows_txt;
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
@@ -118,6 +141,12 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->L = L;
     h->bound = false;
     h->ts = umlh_f32_fwd_config(cfg->num_classes, &h->ctw, &h->wc);
+    h->stw = 1;
+    if (cfg->precision == UMLH_PREC_BF16) {
+        const char* e = getenv("UMLH_BF16_STW");
+        if (h->wc == 8 && e && atoi(e) == 2) h->stw = 2;
+        h->ts = umlh_bf16_fwd_ts(h->wc, h->stw);
+    }
     h->last_rows_img = h->last_rows_txt = 0;
     h->profiling = false;
     memset(&h->buf, 0, sizeof(h->buf));
@@ -290,6 +319,12 @@ int umlh_optimizer_step(int32_t optimizer, float* param, const float* grad, floa
     return UMLH_OK;
 }
 
+int umlh_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n < 0) return fail(UMLH_E_INVALID, "umlh_to_bf16: bad arguments");
+    HIPCHK(umlh_launch_to_bf16(src, dst, n, (hipStream_t)stream), "to_bf16");
+    return UMLH_OK;
+}
+
 // Everything of a step up to (not including) the parameter update.
 static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
                             const umlh_hyper_t* hy, bool want_grad, hipStream_t st, int* n_slabs_head,
@@ -302,6 +337,59 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     const int r0p = nb0 * TS, r1p = nb1 * TS;
     float* H = ws(h, L.h);
     float* dzt = ws(h, L.dzt);
+
+    if (c.precision == UMLH_PREC_BF16) {
+        if ((ri > 0 && !img->feats_bf16) || (rt > 0 && !txt->feats_bf16))
+            return fail(UMLH_E_INVALID, "bf16 mode: batch.feats_bf16 is required (umlh_to_bf16 of the feature table)");
+        u16* w16 = reinterpret_cast<u16*>(ws(h, L.w16));
+        u16* dz16 = reinterpret_cast<u16*>(dzt);
+        mark(h, 0, st);
+        // bf16 shadow of the fp32 master weight, refreshed every call (the caller may have
+        // rewritten w_head: load_state_dict, zero-shot init)
+        HIPCHK(umlh_launch_to_bf16(h->buf.w_head, w16, L.n_head, st), "to_bf16(w_head)");
+        mark(h, 1, st);
+        FwdArgsB fb;
+        memset(&fb, 0, sizeof(fb));
+        SegDescB& b0 = fb.seg[0];
+        SegDescB& b1 = fb.seg[1];
+        if (ri > 0) {
+            b0.feats = static_cast<const u16*>(img->feats_bf16); b0.feat_index = img->index;
+            b0.labels = img->labels; b0.label_index = img->index; b0.ld = c.d_shared; b0.rows = ri;
+            b0.w_over_rows = hy->img_alpha / (float)img->global_rows;
+        }
+        b0.scale_ptr = h->buf.scales; b0.col0 = 0; b0.blk0 = 0;
+        if (rt > 0) {
+            b1.feats = static_cast<const u16*>(txt->feats_bf16); b1.feat_index = txt->index;
+            b1.labels = txt->labels; b1.label_index = txt->index; b1.ld = c.d_shared; b1.rows = rt;
+            b1.w_over_rows = hy->alpha / (float)txt->global_rows;
+        }
+        b1.scale_ptr = h->buf.scales + 1; b1.col0 = r0p; b1.blk0 = nb0;
+        fb.W = w16; fb.C = c.num_classes; fb.K = c.d_shared;
+        fb.dzt = want_grad ? dz16 : nullptr; fb.ldz = 2 * L.ldz;      // the fp32-sized region holds 2x bf16 columns
+        fb.partials = ws(h, L.partials);
+        HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
+        mark(h, 2, st);
+        *n_slabs_head = 0; *n_slabs_proj = 0;
+        if (!want_grad) return UMLH_OK;
+        const int rcols_b = r0p + r1p;
+        int want = L.scap_head;
+        int chunk = (int)round_up((rcols_b + want - 1) / want, 32);
+        if (chunk < 64) chunk = 64;
+        int splits = (rcols_b + chunk - 1) / chunk;
+        DwArgsB g;
+        memset(&g, 0, sizeof(g));
+        g.A = dz16; g.lda = 2 * L.ldz;
+        g.B = img ? static_cast<const u16*>(img->feats_bf16) : nullptr; g.k_rows = img ? img->index : nullptr; g.ldb = c.d_shared;
+        g.B2 = txt ? static_cast<const u16*>(txt->feats_bf16) : nullptr; g.k_rows2 = txt ? txt->index : nullptr; g.ldb2 = c.d_shared;
+        g.out = ws(h, L.slabs_head); g.ldo = c.d_shared;
+        g.M = c.num_classes; g.N = c.d_shared; g.K = rcols_b;
+        g.k_chunk = chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
+        HIPCHK(umlh_bf16_launch_dw(&g, splits, st), "dw_bf16");
+        *n_slabs_head = splits;
+        mark(h, 3, st);
+        mark(h, 4, st);
+        return UMLH_OK;
+    }
 
     mark(h, 0, st);
     if (ri > 0 && c.has_proj) HIPCHK(launch_proj_forward(h, img, H, st), "proj forward");

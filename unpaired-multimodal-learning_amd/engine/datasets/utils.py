@@ -79,6 +79,14 @@ class FeatureTable:
         self.labels = labels.to(device=device, dtype=torch.int64).contiguous()
         self.extra = extra.to(device) if isinstance(extra, torch.Tensor) else extra
         self.device = self.features.device
+        self._bf16 = None
+
+    def features_bf16(self):
+        """bf16 shadow of the table (built once with umlh_to_bf16) for bf16-mode engines."""
+        if self._bf16 is None:
+            import umlh
+            self._bf16 = umlh.to_bf16(self.features)
+        return self._bf16
 
     def __len__(self):
         return self.features.shape[0]

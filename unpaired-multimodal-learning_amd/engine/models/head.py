@@ -175,8 +175,8 @@ class _HeadBase(nn.Module):
         return eng
 
     def _infer_engine(self, rows):
-        for eng in self._engines.values():
-            if min(eng.cfg.max_rows_img, eng.cfg.max_rows_txt) >= rows:
+        for eng in self._engines.values():     # logits / eval always run the exact fp32 kernels
+            if eng.precision == "fp32" and min(eng.cfg.max_rows_img, eng.cfg.max_rows_txt) >= rows:
                 return eng
         cap = 256
         while cap < rows:

@@ -46,8 +46,8 @@ class _RowSource:
     DataLoader yielding the reference's dict / tuple batches) is consumed as dense
     batches moved to ``device``."""
 
-    def __init__(self, loader, device, kind):
-        self.loader, self.device, self.kind = loader, device, kind
+    def __init__(self, loader, device, kind, precision="fp32"):
+        self.loader, self.device, self.kind, self.precision = loader, device, kind, precision
         self.indexed = hasattr(loader, "iter_index")
         self._make_iter = loader.iter_index if self.indexed else loader.__iter__
         self.it = self._make_iter()
@@ -60,7 +60,8 @@ class _RowSource:
         batch, self.it = fetch_next(_Reiter(self._make_iter), self.it)
         if self.indexed:
             t = self.loader.table
-            return umlh.RowBatch(t.features, t.labels, batch)
+            return umlh.RowBatch(t.features, t.labels, batch,
+                                 feats_bf16=t.features_bf16() if self.precision == "bf16" else None)
         if self.kind == "image":
             x, y = batch["img"], batch["label"]
         else:
@@ -90,8 +91,8 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
     if capture_features_during_training:
         print("=> capture_features_during_training is a logging-only diagnostic; not on the fused path (ignored)")
     dev = model.head.weight.device
-    img_src = _RowSource(image_loader, dev, "image") if image_loader is not None else None
-    txt_src = _RowSource(text_loader, dev, "text") if text_loader is not None else None
+    img_src = _RowSource(image_loader, dev, "image", precision) if image_loader is not None else None
+    txt_src = _RowSource(text_loader, dev, "text", precision) if text_loader is not None else None
     engine = model.fused_engine(optimizer, max_rows_img=img_src.capacity if img_src else 32,
                                 max_rows_txt=txt_src.capacity if txt_src else 32, precision=precision)
     scalars = torch.zeros(max_iters, umlh.N_SCALARS, dtype=torch.float32, device=dev)

@@ -25,6 +25,7 @@ class RowBatch:
     index: Optional[torch.Tensor] = None  # [rows] int64, device
     rows: Optional[int] = None
     global_rows: Optional[int] = None   # CE-mean denominator across ranks (default = rows)
+    feats_bf16: Optional[torch.Tensor] = None   # [N, dim] bf16 shadow of feats (bf16 engines)
 
     def n_rows(self) -> int:
         if self.rows is not None:
@@ -60,6 +61,7 @@ class HeadEngine:
         f32 = dict(dtype=torch.float32, device=self.device)
         self.workspace = torch.empty(nbytes // 4, **f32)
         self.has_proj, self.learnable_temp, self.optimizer = bool(has_proj), bool(learnable_temp), optimizer
+        self.precision = precision
         self.d_img, self.d_shared, self.num_classes = d_img, d_shared, num_classes
         self.w_head = torch.zeros(num_classes, d_shared, **f32)
         self.m_head = torch.zeros_like(self.w_head)
@@ -127,7 +129,13 @@ class HeadEngine:
                 raise UmlhError("index shorter than rows")
         elif f.shape[0] < rows:
             raise UmlhError("feature table shorter than rows")
-        return Batch(_ptr(f), _ptr(y), _ptr(b.index), rows, int(b.global_rows or rows))
+        f16 = b.feats_bf16
+        if self.precision == "bf16":
+            if f16 is None:                       # dense batch without a cached shadow: convert now (HIP kernel)
+                f16 = b.feats_bf16 = to_bf16(f)
+            if f16.dtype != torch.bfloat16 or f16.shape != f.shape or not f16.is_contiguous() or f16.device != self.device:
+                raise UmlhError("feats_bf16 must be a contiguous bf16 tensor shaped like feats on the engine's device")
+        return Batch(_ptr(f), _ptr(y), _ptr(b.index), rows, int(b.global_rows or rows), _ptr(f16))
 
     @staticmethod
     def _ref(x):
@@ -220,3 +228,14 @@ def optimizer_step(name: str, param: torch.Tensor, grad: torch.Tensor, m: torch.
     check(lib.umlh_optimizer_step(OPT_IDS[name], _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(),
                                   float(lr), int(step), float(betas[0]), float(betas[1]), float(eps), float(momentum),
                                   float(weight_decay), st), "umlh_optimizer_step")
+
+
+def to_bf16(t: torch.Tensor) -> torch.Tensor:
+    """bf16 shadow (round-to-nearest-even) of an fp32 GPU tensor through ``umlh_to_bf16``."""
+    lib = _lib.load_library()
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != "cuda":
+        raise UmlhError("to_bf16: contiguous fp32 GPU tensor required")
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    st = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    check(lib.umlh_to_bf16(_ptr(t), _ptr(out), t.numel(), st), "umlh_to_bf16")
+    return out
