@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default=os.environ.get("UMLH_PRECISION", "fp32"), choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order-rng", default="device", choices=["device", "torch-cpu"],
+                    help="epoch permutations drawn on the GPU (default) or by the reference-identical CPU sampler")
+    ap.add_argument("--block", type=int, default=25, help="steps per umlh_train_steps call (host prepares the next block meanwhile)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,12 +78,39 @@ def main():
     optimizer = build_optimizer(model.parameters(), "adamw", 1e-3, 0.01)
     scheduler = build_lr_scheduler(optimizer, "cosine", 50, 12800, warmup_type="linear", warmup_lr=1e-5)
     torch.manual_seed(1234 + rank)                                       # per-rank shuffles
-    img_src = _RowSource(FeatureLoader(FeatureTable(x_img, y_img, dev), BATCH, shuffle=True, kind="image"), dev, "image", args.precision)
-    txt_src = _RowSource(FeatureLoader(FeatureTable(x_txt, y_txt, dev), BATCH, shuffle=True, kind="text"), dev, "text", args.precision)
+    img_src = _RowSource(FeatureLoader(FeatureTable(x_img, y_img, dev), BATCH, shuffle=True, kind="image",
+                                       order_rng=args.order_rng), dev, "image", args.precision)
+    txt_src = _RowSource(FeatureLoader(FeatureTable(x_txt, y_txt, dev), BATCH, shuffle=True, kind="text",
+                                       order_rng=args.order_rng), dev, "text", args.precision)
     engine = model.fused_engine(optimizer, BATCH, BATCH, precision=args.precision)
     stepper = umlh.DataParallelStepper(engine)
     stepper.broadcast_parameters([model.head.weight.data])
     scal = torch.zeros(args.warmup + args.steps + 64, umlh.N_SCALARS, device=dev)
+
+    tab_i = img_src.table(args.precision)
+    tab_t = txt_src.table(args.precision)
+
+    def run_steps(k0, n):
+        """n steps through ONE umlh_train_steps call (N=1) or per-step DP stepping (N>1)."""
+        rows = 0
+        if world == 1:
+            done = 0
+            while done < n:
+                m = min(args.block, n - done)
+                bi, bt = [], []
+                for _ in range(m):
+                    bi.append(img_src.next_index())
+                    bt.append(txt_src.next_index())
+                engine.train_steps(tab_i, bi, tab_t, bt, scheduler.lr_table(m), first_step=optimizer.step_count + 1,
+                                   alpha=1.0, scalars_out=scal[k0 + done:k0 + done + m])
+                optimizer.step_count += m
+                scheduler.step(scheduler.last_epoch + m)
+                rows += sum(int(b.numel()) for b in bi) + sum(int(b.numel()) for b in bt)
+                done += m
+            return rows
+        for k in range(n):
+            rows += one_step(k0 + k)
+        return rows
 
     def one_step(k):
         bi, bt = img_src.next(), txt_src.next()
@@ -96,13 +126,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        one_step(k)
+    run_steps(0, args.warmup)
     fence()
     t0 = time.perf_counter()
-    rows = 0
-    for k in range(args.steps):
-        rows += one_step(args.warmup + k)
+    rows = run_steps(args.warmup, args.steps)
+    t_enq = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -160,8 +188,10 @@ def main():
                                       "C=1000, 4096 img + 4096 txt rows/step/GPU, scale 100, zero-shot init, AdamW "
                                       "lr 1e-3 wd 0.01, warm-up 50 + cosine 12800",
                           "n_img_rows": N_IMG, "n_txt_rows": N_TXT, "global_batch": 2 * BATCH * world,
-                          "parallelism": f"dp{world}", "precision_mode": args.precision},
+                          "parallelism": f"dp{world}", "precision_mode": args.precision, "order_rng": args.order_rng,
+                          "steps_per_call": args.block},
                "final_loss": {"img": round(final[0], 4), "txt": round(final[1], 4)},
+               "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
                "roofline": roofline, "cpu_baseline": cpu}
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)

@@ -140,6 +140,23 @@ int  umlh_project(umlh_handle_t h, const umlh_batch_t* batch, float* out, void* 
 int  umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
                      const umlh_hyper_t* hyper, float* scalars_out, void* stream);
 
+/* Many consecutive training steps from device-resident tables with no host work in
+ * between (the whole `for i in range(max_iters)` body of finetune.py:162-195 between two
+ * evaluations).  Step k consumes index[offsets[k] .. offsets[k+1]) of each modality
+ * (offsets: HOST int32[n_steps+1]; a modality with table == NULL is absent), uses
+ * lr[k] (HOST double[n_steps]) and optimizer step number first_step + k, and writes its
+ * scalars to scalars_out + k*UMLH_N_SCALARS (device, may be NULL). */
+typedef struct {
+    const float*   feats;       /* device [table_rows, dim] fp32                           */
+    const void*    feats_bf16;  /* device bf16 shadow (UMLH_PREC_BF16) or NULL             */
+    const int64_t* labels;      /* device [table_rows]                                     */
+    const int64_t* index;       /* device int64: concatenated per-step row ids             */
+    const int32_t* offsets;     /* HOST  int32 [n_steps + 1]                               */
+} umlh_stream_t;
+int  umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_stream_t* txt, int32_t n_steps,
+                      const double* lr, int64_t first_step, float alpha, float img_alpha,
+                      float* scalars_out, void* stream);
+
 /* Data-parallel split of the step: gradients only, laid out as ONE flat fp32
  * buffer [g_head | g_proj | g_scales(2) | scalars(UMLH_N_SCALARS)] inside the
  * workspace, already divided by batch->global_rows so a SUM all-reduce over ranks

@@ -530,6 +530,36 @@ int umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t
     return UMLH_OK;
 }
 
+int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_stream_t* txt, int32_t n_steps,
+                     const double* lr, int64_t first_step, float alpha, float img_alpha, float* scalars_out,
+                     void* stream) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_train_steps: handle not bound");
+    if (n_steps < 0 || !lr || (!img && !txt)) return fail(UMLH_E_INVALID, "umlh_train_steps: bad arguments");
+    if ((img && (!img->offsets || !img->index)) || (txt && (!txt->offsets || !txt->index)))
+        return fail(UMLH_E_INVALID, "umlh_train_steps: index/offsets required");
+    for (int k = 0; k < n_steps; ++k) {
+        umlh_batch_t bi, bt;
+        memset(&bi, 0, sizeof(bi));
+        memset(&bt, 0, sizeof(bt));
+        if (img) {
+            bi.feats = img->feats; bi.feats_bf16 = img->feats_bf16; bi.labels = img->labels;
+            bi.index = img->index + img->offsets[k];
+            bi.rows = bi.global_rows = img->offsets[k + 1] - img->offsets[k];
+        }
+        if (txt) {
+            bt.feats = txt->feats; bt.feats_bf16 = txt->feats_bf16; bt.labels = txt->labels;
+            bt.index = txt->index + txt->offsets[k];
+            bt.rows = bt.global_rows = txt->offsets[k + 1] - txt->offsets[k];
+        }
+        umlh_hyper_t hy;
+        hy.lr = lr[k]; hy.step = first_step + k; hy.alpha = alpha; hy.img_alpha = img_alpha;
+        int rc = umlh_train_step(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy,
+                                 scalars_out ? scalars_out + (size_t)k * UMLH_N_SCALARS : nullptr, stream);
+        if (rc) return rc;
+    }
+    return UMLH_OK;
+}
+
 int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
                    void* stream) {
     int rc = check_step(h, img, txt, hy, "umlh_grad_step");

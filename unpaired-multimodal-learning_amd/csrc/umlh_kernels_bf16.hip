@@ -414,9 +414,13 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
 #define FWDB_CASE(CT, W, S)                                                                          \
     if (ctw == CT && wc == W && stw == S) {                                                          \
         size_t sm = fwd_smem_bytes_b(CT, W, S);                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_bf16<CT, W, S>),    \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);     \
-        if (e != hipSuccess) return (int)e;                                                          \
+        static bool attr_done = false;                                                               \
+        if (!attr_done) {                                                                            \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_bf16<CT, W, S>),\
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+            if (e != hipSuccess) return (int)e;                                                      \
+            attr_done = true;                                                                        \
+        }                                                                                            \
         hipLaunchKernelGGL((fwd_ce_bf16<CT, W, S>), dim3(grid), dim3(512), sm, stream, *a);          \
         return (int)hipGetLastError();                                                               \
     }

@@ -557,9 +557,13 @@ static size_t fwd_smem_bytes(int ctw, int wc) {
 #define FWD_CASE(CT, W)                                                                             \
     if (ctw == CT && wc == W) {                                                                     \
         size_t sm = fwd_smem_bytes(CT, W);                                                          \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_f32<CT, W>),       \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);    \
-        if (e != hipSuccess) return (int)e;                                                         \
+        static bool attr_done = false;                     /* once per instantiation, not per launch */ \
+        if (!attr_done) {                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_f32<CT, W>),   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);\
+            if (e != hipSuccess) return (int)e;                                                     \
+            attr_done = true;                                                                       \
+        }                                                                                           \
         hipLaunchKernelGGL((fwd_ce_f32<CT, W>), dim3(grid), dim3(512), sm, stream, *a);             \
         return (int)hipGetLastError();                                                              \
     }

@@ -105,10 +105,16 @@ class FeatureLoader:
     ``iter_index()`` yields device int64 index vectors (zero-copy batches for the
     fused step); plain iteration yields the reference's batch containers."""
 
-    def __init__(self, table: FeatureTable, batch_size, shuffle=False, drop_last=False, kind="image"):
-        assert kind in ("image", "text")
+    def __init__(self, table: FeatureTable, batch_size, shuffle=False, drop_last=False, kind="image",
+                 order_rng="torch-cpu"):
+        assert kind in ("image", "text") and order_rng in ("torch-cpu", "device")
         self.table, self.batch_size, self.shuffle, self.drop_last, self.kind = table, int(batch_size), shuffle, drop_last, kind
         self.dataset = table
+        # "torch-cpu": the reference's DataLoader order bit for bit (CPU mt19937 randperm + H2D per
+        # epoch, ~20 ms for ImageNet); "device": same distribution, permutation drawn on the GPU
+        # (no host work on the step path) -- for throughput runs where order parity is not asserted
+        self.order_rng = order_rng
+        self._dev_gen = None
 
     def __len__(self):
         n = len(self.table)
@@ -147,9 +153,15 @@ class _IndexIter:
         if self.order is None:
             if ld.shuffle:
                 seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler seed
-                g = torch.Generator()
-                g.manual_seed(seed)
-                self.order = torch.randperm(n, generator=g).to(ld.table.device, non_blocking=True)
+                if ld.order_rng == "device":
+                    if ld._dev_gen is None:
+                        ld._dev_gen = torch.Generator(device=ld.table.device)
+                    ld._dev_gen.manual_seed(seed)
+                    self.order = torch.randperm(n, generator=ld._dev_gen, device=ld.table.device)
+                else:
+                    g = torch.Generator()
+                    g.manual_seed(seed)
+                    self.order = torch.randperm(n, generator=g).to(ld.table.device, non_blocking=True)
             else:
                 self.order = torch.arange(n, dtype=torch.int64, device=ld.table.device)
         if self.pos >= n or (ld.drop_last and self.pos + bs > n):

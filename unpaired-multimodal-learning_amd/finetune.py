@@ -56,6 +56,14 @@ class _RowSource:
     def capacity(self):
         return int(getattr(self.loader, "batch_size", None) or 4096)
 
+    def next_index(self):
+        idx, self.it = fetch_next(_Reiter(self._make_iter), self.it)
+        return idx
+
+    def table(self, precision):
+        t = self.loader.table
+        return (t.features, t.labels, t.features_bf16()) if precision == "bf16" else (t.features, t.labels)
+
     def next(self) -> umlh.RowBatch:
         batch, self.it = fetch_next(_Reiter(self._make_iter), self.it)
         if self.indexed:
@@ -99,13 +107,36 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
     no_improve = 0
     img_alpha = 1.0
     last_i = -1
-    for i in range(max_iters):
-        img_rows = img_src.next() if img_src is not None else None
-        txt_rows = txt_src.next() if txt_src is not None else None
-        engine.train_step(img_rows, txt_rows, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1,
-                          alpha=alpha, img_alpha=img_alpha, scalars_out=scalars[i])
-        optimizer.step_count += 1
-        scheduler.step()
+    blockwise = logger is None and (img_src is None or img_src.indexed) and (txt_src is None or txt_src.indexed)
+    i = 0
+    while i < max_iters:
+        if blockwise:
+            # all steps up to and including the next evaluation point in ONE C call:
+            # no Python, no host sync between steps
+            i_end = i if i % eval_freq == 0 else min(max_iters - 1, (i // eval_freq + 1) * eval_freq)
+            n = i_end - i + 1
+            bi = [] if img_src is not None else None
+            bt = [] if txt_src is not None else None
+            for _ in range(n):                       # image then text per step: the reference's draw order
+                if img_src is not None:
+                    bi.append(img_src.next_index())
+                if txt_src is not None:
+                    bt.append(txt_src.next_index())
+            lrs = scheduler.lr_table(n)
+            engine.train_steps(img_src.table(precision) if img_src else None, bi,
+                               txt_src.table(precision) if txt_src else None, bt, lrs,
+                               first_step=optimizer.step_count + 1, alpha=alpha, img_alpha=img_alpha,
+                               scalars_out=scalars[i:i + n])
+            optimizer.step_count += n
+            scheduler.step(scheduler.last_epoch + n)
+            i = i_end
+        else:
+            img_rows = img_src.next() if img_src is not None else None
+            txt_rows = txt_src.next() if txt_src is not None else None
+            engine.train_step(img_rows, txt_rows, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1,
+                              alpha=alpha, img_alpha=img_alpha, scalars_out=scalars[i])
+            optimizer.step_count += 1
+            scheduler.step()
         last_i = i
         if logger is not None:
             s = scalars[i].cpu()                      # host sync: only when a logger asks for per-step values
@@ -133,6 +164,7 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
             if no_improve >= patience:
                 print(f"=> Early stopping at Iter {i}")
                 break
+        i += 1
     model.load_state_dict(out["model"])
     val_loss, val_acc = validate(model, val_loader, device=device)
     if logger is not None:

@@ -22,7 +22,8 @@ SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_api.cpp"]
 EXPORTS = ["umlh_last_error", "umlh_version", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step",
-           "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16"]
+           "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
+           "umlh_train_steps"]
 
 
 class UmlhError(RuntimeError):
@@ -46,6 +47,11 @@ class Buffers(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("feats", C.c_void_p), ("labels", C.c_void_p), ("index", C.c_void_p),
                 ("rows", C.c_int32), ("global_rows", C.c_int32), ("feats_bf16", C.c_void_p)]
+
+
+class Stream(C.Structure):
+    _fields_ = [("feats", C.c_void_p), ("feats_bf16", C.c_void_p), ("labels", C.c_void_p), ("index", C.c_void_p),
+                ("offsets", C.POINTER(C.c_int32))]
 
 
 class Hyper(C.Structure):
@@ -108,6 +114,8 @@ def load_library():
     lib.umlh_optimizer_step.argtypes = [i32, vp, vp, vp, vp, i64, C.c_double, i64, C.c_double, C.c_double,
                                         C.c_double, C.c_double, C.c_double, vp]
     lib.umlh_to_bf16.argtypes = [vp, vp, i64, vp]
+    lib.umlh_train_steps.argtypes = [vp, C.POINTER(Stream), C.POINTER(Stream), i32, C.POINTER(C.c_double), i64,
+                                     C.c_float, C.c_float, vp, vp]
     lib.umlh_profile_enable.argtypes = [vp, C.c_int]
     lib.umlh_profile_read.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:

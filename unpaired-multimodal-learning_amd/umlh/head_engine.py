@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import Batch, Buffers, Config, Hyper, OPT_IDS, PREC_IDS, N_SCALARS, UmlhError, check
+from ._lib import Batch, Buffers, Config, Hyper, OPT_IDS, PREC_IDS, N_SCALARS, Stream, UmlhError, check
 
 
 @dataclass
@@ -176,6 +176,46 @@ class HeadEngine:
         check(self.lib.umlh_train_step(self.handle, self._ref(bi), self._ref(bt), C.byref(hy), _ptr(so),
                                        self._stream()), "umlh_train_step")
         return so
+
+    def train_steps(self, img_table, img_index_batches, txt_table, txt_index_batches, lrs, first_step: int,
+                    alpha: float = 1.0, img_alpha: float = 1.0, scalars_out: Optional[torch.Tensor] = None) -> None:
+        """``len(lrs)`` consecutive fused steps with no Python in between (umlh_train_steps).
+        ``*_table`` = (feats, labels[, feats_bf16]) device tensors or None; ``*_index_batches``
+        = one int64 device index vector per step."""
+        n = len(lrs)
+
+        def stream(table, batches, dim, cap):
+            if table is None:
+                return None, None
+            f, y = table[0], table[1]
+            f16 = table[2] if len(table) > 2 else None
+            if f.dtype != torch.float32 or not f.is_contiguous() or f.shape[1] != dim or y.dtype != torch.int64:
+                raise UmlhError("train_steps: table must be contiguous fp32 [N,dim] + int64 labels")
+            if self.precision == "bf16" and (f16 is None or f16.dtype != torch.bfloat16 or f16.shape != f.shape):
+                raise UmlhError("train_steps: bf16 engine needs the table's bf16 shadow")
+            if len(batches) != n:
+                raise UmlhError("train_steps: one index vector per step required")
+            sizes = [int(b.numel()) for b in batches]
+            if max(sizes) > cap:
+                raise UmlhError(f"train_steps: batch of {max(sizes)} rows exceeds capacity {cap}")
+            idx = torch.cat(batches) if n > 1 else batches[0].contiguous()
+            offs = (C.c_int32 * (n + 1))()
+            acc = 0
+            for k, sz in enumerate(sizes):
+                offs[k] = acc
+                acc += sz
+            offs[n] = acc
+            keep = (f, y, f16, idx, offs)
+            return Stream(_ptr(f), _ptr(f16), _ptr(y), _ptr(idx), offs), keep
+
+        si, keep_i = stream(img_table, img_index_batches, self.d_img, self.cfg.max_rows_img)
+        st, keep_t = stream(txt_table, txt_index_batches, self.d_shared, self.cfg.max_rows_txt)
+        lr_arr = (C.c_double * n)(*[float(x) for x in lrs])
+        check(self.lib.umlh_train_steps(self.handle, self._ref(si), self._ref(st), n, lr_arr, int(first_step),
+                                        float(alpha), float(img_alpha), _ptr(scalars_out), self._stream()),
+              "umlh_train_steps")
+        # index tensors must outlive the enqueued kernels: keep them until the next call
+        self._keepalive = (keep_i, keep_t)
 
     def grad_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], alpha: float = 1.0,
                   img_alpha: float = 1.0) -> torch.Tensor:
