@@ -42,9 +42,9 @@ def _rb(x, y, idx=None):
     return umlh.RowBatch(T(x, torch.float32), T(y, torch.int64), None if idx is None else T(idx, torch.int64))
 
 
-@pytest.mark.parametrize("d,C,bi,bt,scale,stw", [(64, 10, 70, 33, 30.0, 1), (128, 100, 50, 64, 100.0, 1),
-                                                 (512, 1000, 300, 257, 100.0, 1), (512, 1000, 300, 257, 100.0, 2),
-                                                 (96, 397, 40, 0, 50.0, 1), (256, 37, 0, 90, 20.0, 1)])
+@pytest.mark.parametrize("d,C,bi,bt,scale,stw", [(128, 10, 70, 33, 30.0, 1), (128, 100, 50, 64, 100.0, 1),
+                                                 (512, 1000, 300, 257, 100.0, 1), (512, 1000, 300, 257, 100.0, 2), (1024, 1000, 70, 300, 100.0, 1),
+                                                 (384, 397, 40, 0, 50.0, 1), (256, 37, 0, 90, 20.0, 1)])
 def test_bf16_grad_step_vs_oracle_on_rounded_operands(d, C, bi, bt, scale, stw, monkeypatch):
     import umlh
     monkeypatch.setenv("UMLH_BF16_STW", str(stw))
@@ -92,7 +92,7 @@ def test_bf16_requires_linear_head_and_k_multiple_of_32():
     with pytest.raises(umlh.UmlhError):
         umlh.HeadEngine(48, 64, 10, has_proj=True, precision="bf16", device=DEV)
     with pytest.raises(umlh.UmlhError):
-        umlh.HeadEngine(40, 40, 10, precision="bf16", device=DEV)
+        umlh.HeadEngine(96, 96, 10, precision="bf16", device=DEV)
 
 
 def test_bf16_training_accuracy_parity_with_fp32():

@@ -22,6 +22,8 @@ int umlh_launch_zero_shot(const float* feats, const int64_t* labels, long long n
                           hipStream_t stream);
 int umlh_launch_to_bf16(const float* src, void* dst, long long n, hipStream_t stream);
 int umlh_bf16_fwd_ts(int wc, int stw);
+int umlh_launch_w_shadow(const float* w, void* dst, int C, int K, int cpad, hipStream_t stream);
+int umlh_launch_iota(long long* dst, long long n, hipStream_t stream);
 }
 
 // argument blocks of the bf16 kernels (layout must match umlh_kernels_bf16.hip)
@@ -30,10 +32,10 @@ struct SegDescB {
     const u16* feats; const int64_t* feat_index; const int64_t* labels; const int64_t* label_index;
     const float* scale_ptr; int rows, ld, col0, blk0; float w_over_rows;
 };
-struct FwdArgsB { SegDescB seg[2]; const u16* W; int C, K; u16* dzt; int ldz; float* partials; };
+struct FwdArgsB { SegDescB seg[2]; const u16* W; int C, K; u16* dzt; int crows; float* partials; int dbg; };
 struct DwArgsB {
     const u16* A; const u16* B; const int64_t* k_rows; int ldb; const u16* B2; const int64_t* k_rows2; int ldb2;
-    float* out; int M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2; long long slab_stride;
+    float* out; const u16* zeros; int M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit; long long slab_stride;
 };
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
@@ -53,7 +55,7 @@ static int fail(int code, const char* fmt, ...) {
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 struct Layout {                 // workspace partition, in floats from the base
-    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, total;
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, iota, zeros, total;
     int rcap_img, rcap_txt, ldz;     // padded row capacities
     int scap_head, scap_proj;        // split-K slab capacities
     long long n_head, n_proj;        // parameter counts
@@ -75,25 +77,30 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     if (c.optimizer < UMLH_OPT_SGD || c.optimizer > UMLH_OPT_ADAMW) return false;
     if (c.precision != UMLH_PREC_FP32 && c.precision != UMLH_PREC_BF16) return false;
     // bf16 mode: linear head only (img_proj GEMMs run in fp32 mode), K a multiple of the 32-wide chunk
-    if (c.precision == UMLH_PREC_BF16 && (c.has_proj || c.d_shared % 32 != 0)) return false;
+    if (c.precision == UMLH_PREC_BF16 && (c.has_proj || c.d_shared % 128 != 0)) return false;
     L.rcap_img = (int)round_up(c.max_rows_img, 256);
     L.rcap_txt = (int)round_up(c.max_rows_txt, 256);
     L.ldz = L.rcap_img + L.rcap_txt;
     L.n_head = (long long)c.num_classes * c.d_shared;
     L.n_proj = c.has_proj ? (long long)c.d_shared * c.d_img : 0;
     L.scap_head = split_cap(c.num_classes, c.d_shared);
+    if (c.precision == UMLH_PREC_BF16 && L.scap_head < (L.ldz + 4095) / 4096) L.scap_head = (L.ldz + 4095) / 4096;
     L.scap_proj = c.has_proj ? split_cap(c.d_shared, c.d_img) : 0;
     L.max_blocks = L.ldz / 32 + 2;
     long long off = 0;
     auto take = [&](long long n) { long long o = off; off += round_up(n, 64); return o; };
-    L.dzt = take((long long)c.num_classes * L.ldz);
+    // fp32: dZ^T [C][ldz] floats.  bf16: [ldz/64][crows][64] shorts, crows = C rounded up to 128
+    L.dzt = take(c.precision == UMLH_PREC_BF16 ? (round_up(c.num_classes, 128) * (long long)L.ldz + 1) / 2
+                                               : (long long)c.num_classes * L.ldz);
     L.h = take(c.has_proj ? (long long)L.rcap_img * c.d_shared : 0);
     L.dht = take(c.has_proj ? (long long)c.d_shared * L.rcap_img : 0);
     L.slabs_head = take((long long)L.scap_head * L.n_head);
     L.slabs_proj = take((long long)L.scap_proj * L.n_proj);
     L.partials = take((long long)L.max_blocks * 4);
     L.grads = take(L.n_head + L.n_proj + 2 + UMLH_N_SCALARS);
-    L.w16 = take(c.precision == UMLH_PREC_BF16 ? (L.n_head + 1) / 2 : 0);   // bf16 shadow of w_head
+    L.w16 = take(c.precision == UMLH_PREC_BF16 ? 1024LL * c.d_shared / 2 : 0);   // bf16 chunk-major shadow of w_head (<= 1024 class rows)
+    L.iota = take(c.precision == UMLH_PREC_BF16 ? 2LL * (L.rcap_img > L.rcap_txt ? L.rcap_img : L.rcap_txt) : 0);   // int64 0..cap-1
+    L.zeros = take(64);
     L.total = off;
     return true;
 }
@@ -107,6 +114,7 @@ struct umlh_handle_s {
     int stw;                    // bf16: 32-sample tiles per wave
     // state carried from umlh_grad_step to umlh_apply_update
     int last_rows_img, last_rows_txt;
+    bool iota_ready;            // bf16: identity row-id table in the workspace initialised
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
     bool profiling;
 };
@@ -143,8 +151,11 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->ts = umlh_f32_fwd_config(cfg->num_classes, &h->ctw, &h->wc);
     h->stw = 1;
     if (cfg->precision == UMLH_PREC_BF16) {
+        // two 32-sample tiles per wave halve the L2->CU stream of the head weight (the bound of the
+        // forward kernel at C ~ 1000) once there are enough rows to keep >= 128 CUs busy
         const char* e = getenv("UMLH_BF16_STW");
-        if (h->wc == 8 && e && atoi(e) == 2) h->stw = 2;
+        int want = e ? atoi(e) : ((cfg->max_rows_img + cfg->max_rows_txt) >= 4096 ? 2 : 1);
+        if (h->wc == 8 && h->ctw >= 2 && want == 2) h->stw = 2;
         h->ts = umlh_bf16_fwd_ts(h->wc, h->stw);
     }
     h->last_rows_img = h->last_rows_txt = 0;
@@ -198,6 +209,7 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
     if ((reinterpret_cast<uintptr_t>(b->workspace) & 255) != 0) return fail(UMLH_E_INVALID, "umlh_bind: workspace must be 256-B aligned");
     h->buf = *b;
     h->bound = true;
+    h->iota_ready = false;
     return UMLH_OK;
 }
 
@@ -346,7 +358,9 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         mark(h, 0, st);
         // bf16 shadow of the fp32 master weight, refreshed every call (the caller may have
         // rewritten w_head: load_state_dict, zero-shot init)
-        HIPCHK(umlh_launch_to_bf16(h->buf.w_head, w16, L.n_head, st), "to_bf16(w_head)");
+        const int cpad = 32 * h->ctw * h->wc;
+        const int crows = (int)round_up(c.num_classes, 128);
+        HIPCHK(umlh_launch_w_shadow(h->buf.w_head, w16, c.num_classes, c.d_shared, cpad, st), "w_shadow");
         mark(h, 1, st);
         FwdArgsB fb;
         memset(&fb, 0, sizeof(fb));
@@ -365,25 +379,41 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         }
         b1.scale_ptr = h->buf.scales + 1; b1.col0 = r0p; b1.blk0 = nb0;
         fb.W = w16; fb.C = c.num_classes; fb.K = c.d_shared;
-        fb.dzt = want_grad ? dz16 : nullptr; fb.ldz = 2 * L.ldz;      // the fp32-sized region holds 2x bf16 columns
+        fb.dzt = want_grad ? dz16 : nullptr; fb.crows = crows;
         fb.partials = ws(h, L.partials);
+        { const char* e = getenv("UMLH_DBG_FWD"); fb.dbg = e ? atoi(e) : 0; }
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
         mark(h, 2, st);
         *n_slabs_head = 0; *n_slabs_proj = 0;
         if (!want_grad) return UMLH_OK;
         const int rcols_b = r0p + r1p;
         int want = L.scap_head;
-        int chunk = (int)round_up((rcols_b + want - 1) / want, 32);
-        if (chunk < 64) chunk = 64;
+        int chunk = (int)round_up((rcols_b + want - 1) / want, 256);      // 4-stage pipeline: multiples of 4 x 64 columns
+        if (chunk > 4096) chunk = 4096;                                    // row ids of a split live in LDS
+        if ((rcols_b + chunk - 1) / chunk > L.scap_head)
+            return fail(UMLH_E_INVALID, "bf16 dW: %d reduction rows need more than %d split-K slabs", rcols_b, L.scap_head);
         int splits = (rcols_b + chunk - 1) / chunk;
+        // the dW loader is branch-free: every pointer must be dereferenceable, also for an absent
+        // modality or a dense (index-less) batch -> identity row ids from the workspace
+        int64_t* iota = reinterpret_cast<int64_t*>(ws(h, L.iota));
+        if (!h->iota_ready) {
+            long long n = L.rcap_img > L.rcap_txt ? L.rcap_img : L.rcap_txt;
+            HIPCHK(umlh_launch_iota(reinterpret_cast<long long*>(iota), n, st), "iota");
+            HIPCHK((int)hipMemsetAsync(ws(h, L.zeros), 0, 64 * sizeof(float), st), "zero page");
+            h->iota_ready = true;
+        }
+        const u16* any16 = ri > 0 ? static_cast<const u16*>(img->feats_bf16) : static_cast<const u16*>(txt->feats_bf16);
         DwArgsB g;
         memset(&g, 0, sizeof(g));
-        g.A = dz16; g.lda = 2 * L.ldz;
-        g.B = img ? static_cast<const u16*>(img->feats_bf16) : nullptr; g.k_rows = img ? img->index : nullptr; g.ldb = c.d_shared;
-        g.B2 = txt ? static_cast<const u16*>(txt->feats_bf16) : nullptr; g.k_rows2 = txt ? txt->index : nullptr; g.ldb2 = c.d_shared;
+        g.A = dz16; g.lda = crows; g.zeros = reinterpret_cast<const u16*>(ws(h, L.zeros));
+        g.B = ri > 0 ? static_cast<const u16*>(img->feats_bf16) : any16;
+        g.k_rows = (ri > 0 && img->index) ? img->index : iota; g.ldb = c.d_shared;
+        g.B2 = rt > 0 ? static_cast<const u16*>(txt->feats_bf16) : any16;
+        g.k_rows2 = (rt > 0 && txt->index) ? txt->index : iota; g.ldb2 = c.d_shared;
         g.out = ws(h, L.slabs_head); g.ldo = c.d_shared;
         g.M = c.num_classes; g.N = c.d_shared; g.K = rcols_b;
         g.k_chunk = chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
+        g.nsplit = splits;
         HIPCHK(umlh_bf16_launch_dw(&g, splits, st), "dw_bf16");
         *n_slabs_head = splits;
         mark(h, 3, st);

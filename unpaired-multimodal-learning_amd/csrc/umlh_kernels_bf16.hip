@@ -41,6 +41,40 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void iota_kernel(long long* dst, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = i;
+}
+
+// Head-weight shadow for the forward kernel: bf16, MFMA-FRAGMENT-MAJOR
+//   [K/16 k-step][CPAD/32 class tile][64 lanes][8 bf16]
+// lane l of tile t, k-step s holds W[32 t + (l & 31)][16 s + 8 (l >> 5) .. +8): exactly the A
+// operand of v_mfma_f32_32x32x16_bf16, so a wave fetches one operand with ONE fully coalesced
+// 1-KiB global_load_dwordx4 straight into registers (no LDS round trip for the streamed
+// operand).  Class rows >= C are zero.
+__global__ __launch_bounds__(256) void w_shadow_kernel(const float* __restrict__ w, u16* __restrict__ dst, int C, int K,
+                                                       int cpad) {
+    long long piece = (long long)blockIdx.x * 256 + threadIdx.x;          // one lane-fragment (16 B)
+    const int tiles = cpad / 32;
+    long long total = (long long)(K / 16) * tiles * 64;
+    if (piece >= total) return;
+    int lane = (int)(piece & 63);
+    int tile = (int)((piece >> 6) % tiles);
+    int ks = (int)((piece >> 6) / tiles);
+    int cls = tile * 32 + (lane & 31);
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (cls < C) {
+        const float* src = w + (size_t)cls * K + ks * 16 + 8 * (lane >> 5);
+        f32x4v a = *reinterpret_cast<const f32x4v*>(src);
+        f32x4v b = *reinterpret_cast<const f32x4v*>(src + 4);
+        o[0] = f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
+        o[1] = f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
+        o[2] = f2bf(b[0]) | ((unsigned)f2bf(b[1]) << 16);
+        o[3] = f2bf(b[2]) | ((unsigned)f2bf(b[3]) << 16);
+    }
+    *reinterpret_cast<u32x4*>(dst + piece * 8) = o;
+}
+
 struct SegDescB {
     const u16*     feats;        // [*, ld] bf16
     const int64_t* feat_index;
@@ -53,36 +87,42 @@ struct SegDescB {
 
 struct FwdArgsB {
     SegDescB seg[2];
-    const u16* W;                // [C, K] bf16 shadow of the head weight
+    const u16* W;                // bf16 fragment-major shadow of the head weight (w_shadow_kernel)
     int   C, K;
-    u16*  dzt;                   // [C, ldz] bf16 dZ^T, NULL = eval
-    int   ldz;
+    u16*  dzt;                   // bf16 dZ^T, column-chunk-major [cols/64][crows][64]; NULL = eval
+    int   crows;                 // class rows per column chunk (C rounded up to 128)
     float* partials;
+    int   dbg;                   // timing-only ablations: 1 = main loop only, 2 = epilogue only
 };
 
 struct DwArgsB {
-    const u16* A;                // dZ^T [M=C, lda] bf16
+    const u16* A;                // dZ^T bf16, column-chunk-major [K/64][lda=crows][64]
     const u16* B;  const int64_t* k_rows;  int ldb;     // image-side feature rows
     const u16* B2; const int64_t* k_rows2; int ldb2;    // text-side feature rows (k >= k_switch)
     float* out;                  // fp32 slabs [splits][M][ldo]
-    int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2;
+    const u16* zeros;            // >= 16 B of zeros (source of masked loads)
+    int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit;
     long long slab_stride;
 };
 
 // --------------------------------------------------------------------------- //
 // fused forward + cross entropy, bf16 operands
 // --------------------------------------------------------------------------- //
+// Streamed operand W: global -> registers (fragment-major shadow, PD k-steps deep ring per wave,
+// 16 KiB in flight per wave).  Shared operand X: the block's TS sample rows stay resident in LDS
+// for a K-block of XK and every wave reads its B fragment with one ds_read_b128 per k-step.
 template <int CTW, int WC, int STW>
 __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     constexpr int WS = 8 / WC;
     constexpr int CPAD = 32 * CTW * WC;
     constexpr int TS = 32 * STW * WS;
-    constexpr int NPW = (CPAD * 4 + 511) / 512;     // 16-B pieces of the W chunk per thread
-    constexpr int NPX = (TS * 4 + 511) / 512;
+    constexpr int XK = WS <= 2 ? 512 : (WS == 4 ? 256 : 128);   // K-block resident in LDS
+    constexpr int XRS = XK + 8;                                  // row stride (shorts): odd multiple of 16 B
+    constexpr int PD = STW == 1 ? 8 : 4;                         // k-steps of W fragments in flight (ring depth)
+    constexpr int NPX = (TS * (XK / 8)) / 512;                   // 16-B pieces of the X block per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Wt = reinterpret_cast<u16*>(smem_raw);                  // [CPAD][RSB]
-    u16* Xt = Wt + CPAD * RSB;                                   // [TS][RSB]
-    float* red = reinterpret_cast<float*>(Xt + TS * RSB);        // [WS][WC][32][4]
+    u16* Xt = reinterpret_cast<u16*>(smem_raw);                  // [TS][XRS]
+    float* red = reinterpret_cast<float*>(Xt + TS * XRS);        // [WS][WC][32][4]
     float* red2 = red + 8 * 32 * 4;                              // [WS][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,22 +133,15 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     const int row0 = ((int)blockIdx.x - sg.blk0) * TS;
     const int C = a.C, K = a.K;
 
-    const u16* wsrc[NPW];
+    // X pieces of this thread: piece p -> row p / (XK/8), 16-B column p % (XK/8).  Rows past the
+    // segment are clamped to its last row (finite garbage the epilogue discards).
     const u16* xsrc[NPX];
 #pragma unroll
-    for (int q = 0; q < NPW; ++q) {
-        int p = tid + 512 * q, cls = p >> 2;
-        wsrc[q] = (p < CPAD * 4 && cls < C) ? a.W + (size_t)cls * K + 8 * (p & 3) : nullptr;
-    }
-#pragma unroll
     for (int q = 0; q < NPX; ++q) {
-        int p = tid + 512 * q, smp = p >> 2, r = row0 + smp;
-        const u16* s = nullptr;
-        if (p < TS * 4 && r < sg.rows) {
-            int64_t rid = sg.feat_index ? sg.feat_index[r] : (int64_t)r;
-            s = sg.feats + (size_t)rid * sg.ld + 8 * (p & 3);
-        }
-        xsrc[q] = s;
+        int p = tid + 512 * q;
+        int r = min(row0 + p / (XK / 8), sg.rows - 1);
+        int64_t rid = sg.feat_index ? sg.feat_index[r] : (int64_t)r;
+        xsrc[q] = sg.feats + (size_t)rid * sg.ld + 8 * (p % (XK / 8));
     }
 
     f32x16 acc[CTW][STW];
@@ -119,49 +152,73 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ct][st][i] = 0.f;
 
-    u32x4 wreg[NPW], xreg[NPX];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < NPW; ++q) wreg[q] = wsrc[q] ? *reinterpret_cast<const u32x4*>(wsrc[q] + k0) : zero4;
-#pragma unroll
-        for (int q = 0; q < NPX; ++q) xreg[q] = xsrc[q] ? *reinterpret_cast<const u32x4*>(xsrc[q] + k0) : zero4;
+    const int nks = K / 16;                                      // total k-steps (multiple of PD)
+    // fragment (k-step ks, class tile t) = 1 KiB at W + ((ks * CPAD/32 + t) * 64 + lane) * 8
+    const u16* wlane = a.W + ((size_t)(wc * CTW) * 64 + lane) * 8;
+    auto wfrag = [&](int ks, int ct) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(wlane + ((size_t)ks * (CPAD / 32) + ct) * 512);
     };
-    auto lstore = [&]() {
+    bf16x8 ring[PD][CTW];
 #pragma unroll
-        for (int q = 0; q < NPW; ++q) {
-            int p = tid + 512 * q;
-            if (p < CPAD * 4) *reinterpret_cast<u32x4*>(Wt + (p >> 2) * RSB + 8 * (p & 3)) = wreg[q];
+    for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) ring[d][ct] = wfrag(min(d, nks - 1), ct);
+
+    for (int kb0 = 0; kb0 < (a.dbg == 2 ? 0 : K); kb0 += XK) {
+        const int kbw = min(XK, K - kb0);                        // multiple of 128
+        // ---- stage the X block: global -> registers -> LDS ----
+        u32x4 xr[NPX];
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) {
+            int col = 8 * ((tid + 512 * q) % (XK / 8));
+            xr[q] = *reinterpret_cast<const u32x4*>(xsrc[q] + kb0 + min(col, kbw - 8) - col);
         }
+        __syncthreads();                                         // previous block fully consumed
 #pragma unroll
         for (int q = 0; q < NPX; ++q) {
             int p = tid + 512 * q;
-            if (p < TS * 4) *reinterpret_cast<u32x4*>(Xt + (p >> 2) * RSB + 8 * (p & 3)) = xreg[q];
+            *reinterpret_cast<u32x4*>(Xt + (p / (XK / 8)) * XRS + 8 * (p % (XK / 8))) = xr[q];
         }
-    };
-
-    gload(0);
-    for (int k0 = 0; k0 < K; k0 += KTB) {
         __syncthreads();
-        lstore();
-        __syncthreads();
-        if (k0 + KTB < K) gload(k0 + KTB);
+        // ---- k-steps of this block ----
+        const int ks0 = kb0 / 16, nst = kbw / 16;                // nst is a multiple of PD
+        const u16* xrow = Xt + (ws * 32 * STW + l31) * XRS + h * 8;
+        for (int s = 0; s < nst; s += PD) {
 #pragma unroll
-        for (int s = 0; s < KTB / 16; ++s) {
-            bf16x8 b[STW];
-#pragma unroll
-            for (int st = 0; st < STW; ++st)
-                b[st] = *reinterpret_cast<const bf16x8*>(Xt + (ws * 32 * STW + st * 32 + l31) * RSB + s * 16 + h * 8);
-#pragma unroll
-            for (int ct = 0; ct < CTW; ++ct) {
-                const bf16x8 av = *reinterpret_cast<const bf16x8*>(Wt + ((wc * CTW + ct) * 32 + l31) * RSB + s * 16 + h * 8);
+            for (int d = 0; d < PD; ++d) {
+                bf16x8 b[STW];
 #pragma unroll
                 for (int st = 0; st < STW; ++st)
-                    acc[ct][st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[st], acc[ct][st], 0, 0, 0);
+                    b[st] = *reinterpret_cast<const bf16x8*>(xrow + st * 32 * XRS + (s + d) * 16);
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                    for (int st = 0; st < STW; ++st)
+                        acc[ct][st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[d][ct], b[st], acc[ct][st], 0, 0, 0);
+                const int nxt = min(ks0 + s + d + PD, nks - 1);  // refill this slot PD k-steps ahead
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) ring[d][ct] = wfrag(nxt, ct);
+                // pin the emitted order per k-step: B read, its MFMAs, then the slot's refill loads
+                // (left alone, hipcc sinks all refills to the end of the group, which leaves the
+                // next group's first fragment zero time to arrive)
+                __builtin_amdgcn_sched_group_barrier(0x100, STW, 0);        // B reads
+                __builtin_amdgcn_sched_group_barrier(0x008, CTW * STW, 0);  // MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x020, CTW, 0);    // CTW VMEM reads
             }
         }
     }
 
+    if (a.dbg == 1) {                                  // ablation: keep the accumulators live, skip the epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int st = 0; st < STW; ++st)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += acc[ct][st][i];
+        if (t == 123.456f) a.partials[0] = t;
+        return;
+    }
     // ---------------- epilogue (per 32-sample tile of this wave) ----------------
     const float scale = *sg.scale_ptr;
     const float NEG_INF = -__builtin_huge_valf();
@@ -251,7 +308,8 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
                     unsigned packed = odd ? (f2bf(recv) | ((unsigned)f2bf(d1) << 16))
                                           : (f2bf(d0) | ((unsigned)f2bf(recv) << 16));
                     int cls = odd ? c1 : c0;
-                    if (cls < C) *reinterpret_cast<unsigned*>(a.dzt + (size_t)cls * a.ldz + colpair) = packed;
+                    if (cls < C)
+                        *reinterpret_cast<unsigned*>(a.dzt + ((size_t)(colpair >> 6) * a.crows + cls) * 64 + (colpair & 63)) = packed;
                 }
         }
         if (wc == 0 && h == 0 && valid) {
@@ -284,18 +342,44 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 // column) comes from the hardware transposing read ds_read_b64_tr_b16.
 // --------------------------------------------------------------------------- //
 constexpr int DBM = 128, DBN = 128;
+constexpr int DKT = 64;     // reduction rows (dZ^T columns) per chunk = one column chunk of dZ^T
+constexpr int RSA = 72;     // shorts per LDS row of the dZ^T tile: 128 B data + 16 B pad (9 x 16 B: conflict-free b128)
 constexpr int RSF = 160;    // shorts per LDS row of the F tile: 256 B data + 64 B pad (4 k-rows -> 4 bank quarters)
 
+constexpr int DNS = 4;      // register stages: 3 chunks (96 KiB per CU) in flight while one is consumed
+constexpr int DIDS = 4096;  // max reduction rows per workgroup (row ids staged in LDS)
+
 __global__ __launch_bounds__(256) void dw_bf16(DwArgsB g) {
-    __shared__ __attribute__((aligned(16))) u16 At[DBM * RSB];
-    __shared__ __attribute__((aligned(16))) u16 Ft[KTB * RSF];
+    __shared__ __attribute__((aligned(16))) u16 At[DBM * RSA];
+    __shared__ __attribute__((aligned(16))) u16 Ft[DKT * RSF];
+    __shared__ int ids[DIDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int m0 = blockIdx.y * DBM, n0 = blockIdx.x * DBN;
-    const int kb = blockIdx.z * g.k_chunk;
+    // XCD-aware decode of the 1-D grid: workgroups b and b+8 share an XCD (round-robin dispatch),
+    // so split z = b % nsplit_pad keeps every tile of one K-split -- which all re-read the same
+    // dZ^T columns and feature rows -- on ONE XCD's L2 (speed only; any placement is correct).
+    const int nx = (g.N + DBN - 1) / DBN, ny = (g.M + DBM - 1) / DBM;
+    const int bid = blockIdx.x;
+    const int z = bid % g.nsplit, t = bid / g.nsplit;
+    const int m0 = (t / nx) * DBM, n0 = (t % nx) * DBN;
+    (void)ny;
+    const int kb = z * g.k_chunk;                       // multiples of DKT
     const int ke = min(g.K, kb + g.k_chunk);
+    const int nchunks = g.k_chunk / DKT;                // multiple of DNS
+
+    // row ids of this split -> LDS once (no dependent global loads inside the pipeline)
+    for (int i = tid; i < g.k_chunk; i += 256) {
+        int k = kb + i;
+        bool seg2 = k >= g.k_switch;
+        int kl = seg2 ? k - g.k_switch : k;
+        int lim = seg2 ? g.k_valid2 : g.k_valid1;
+        const int64_t* ip = seg2 ? g.k_rows2 : g.k_rows;
+        bool valid = k < ke && kl < lim;
+        ids[i] = valid ? (int)ip[kl] : -1;              // -1: masked row
+    }
+    __syncthreads();
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -305,68 +389,53 @@ __global__ __launch_bounds__(256) void dw_bf16(DwArgsB g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    u32x4 areg[2], freg[2];
-    const u16* a_src[2];
+    struct Stage { u32x4 a[4]; u32x4 f[4]; };
+    Stage st[DNS];
+    // Branch-free loads: addresses clamped into valid memory, masked values zeroed by selects.
+    const int mclamp = g.M - 1 - m0;
+    auto gload = [&](Stage& sg, int c) {
+        const int k0 = kb + c * DKT;
+        const u16* abase = g.A + ((size_t)(k0 >> 6) * g.lda + m0) * 64;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int p = tid + 256 * q, row = p >> 2, m = m0 + row;
-        a_src[q] = m < g.M ? g.A + (size_t)m * g.lda + 8 * (p & 3) : nullptr;
-    }
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            int p = tid + 256 * q;
-            areg[q] = (a_src[q] && k0 + 8 * (p & 3) < ke) ? *reinterpret_cast<const u32x4*>(a_src[q] + k0) : zero4;
-            int kk = p >> 4, nn = n0 + 8 * (p & 15), k = k0 + kk;
-            u32x4 v = zero4;
-            if (k < ke && nn < g.N) {
-                if (k < g.k_switch) {
-                    if (k < g.k_valid1) {
-                        int64_t rid = g.k_rows ? g.k_rows[k] : (int64_t)k;
-                        v = *reinterpret_cast<const u32x4*>(g.B + (size_t)rid * g.ldb + nn);
-                    }
-                } else {
-                    int kl = k - g.k_switch;
-                    if (kl < g.k_valid2) {
-                        int64_t rid = g.k_rows2 ? g.k_rows2[kl] : (int64_t)kl;
-                        v = *reinterpret_cast<const u32x4*>(g.B2 + (size_t)rid * g.ldb2 + nn);
-                    }
-                }
-            }
-            freg[q] = v;
+        for (int q = 0; q < 4; ++q) {
+            int p = tid + 256 * q;                       // A: row p>>3, piece p&7;  F: row p>>4, piece p&15
+            int arow = min(p >> 3, mclamp);              // rows >= M: garbage that is never stored
+            // masked pieces are READ FROM A ZERO PAGE (no select on the loaded value: a select
+            // would make the compiler wait for the load right here and serialise the pipeline)
+            const u16* ap = (k0 + 8 * (p & 7) < ke) ? abase + (size_t)arow * 64 + 8 * (p & 7) : g.zeros;
+            sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
+            int kk = c * DKT + (p >> 4);
+            int rid = ids[kk];
+            bool seg2 = kb + kk >= g.k_switch;
+            const u16* fb = seg2 ? g.B2 : g.B;
+            int ld = seg2 ? g.ldb2 : g.ldb;
+            int ncol = n0 + 8 * (p & 15);
+            const u16* fp = (rid >= 0 && ncol < g.N) ? fb + (size_t)rid * ld + ncol : g.zeros;
+            sg.f[q] = *reinterpret_cast<const u32x4*>(fp);
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](const Stage& sg) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             int p = tid + 256 * q;
-            *reinterpret_cast<u32x4*>(At + (p >> 2) * RSB + 8 * (p & 3)) = areg[q];
-            *reinterpret_cast<u32x4*>(Ft + (p >> 4) * RSF + 8 * (p & 15)) = freg[q];
+            *reinterpret_cast<u32x4*>(At + (p >> 3) * RSA + 8 * (p & 7)) = sg.a[q];
+            *reinterpret_cast<u32x4*>(Ft + (p >> 4) * RSF + 8 * (p & 15)) = sg.f[q];
         }
     };
-
-    if (kb < ke) gload(kb);
-    for (int k0 = kb; k0 < ke; k0 += KTB) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (k0 + KTB < ke) gload(k0 + KTB);
+    auto compute = [&]() {
 #pragma unroll
-        for (int s = 0; s < KTB / 16; ++s) {
+        for (int s = 0; s < DKT / 16; ++s) {
             bf16x8 av[2], bv[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                av[i] = *reinterpret_cast<const bf16x8*>(At + (wm * 64 + i * 32 + l31) * RSB + s * 16 + h * 8);
+                av[i] = *reinterpret_cast<const bf16x8*>(At + (wm * 64 + i * 32 + l31) * RSA + s * 16 + h * 8);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // 16-lane group g16: column block (g16&1) of the 32-wide tile, k half h = g16>>1;
                 // lane 4q+p addresses row q, columns 4p..4p+3; it receives column (lane&15), rows 0..3.
                 const u16* base = Ft + (s * 16 + 8 * h + q4) * RSF + wn * 64 + j * 32 + (g16 & 1) * 16 + 4 * p4;
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(base));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(base + 4 * RSF));
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * RSF));
                 s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 bv[j] = __builtin_bit_cast(bf16x8, v);
             }
@@ -376,9 +445,23 @@ __global__ __launch_bounds__(256) void dw_bf16(DwArgsB g) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    const int lastc = nchunks - 1;
+#pragma unroll
+    for (int d = 0; d < DNS; ++d) gload(st[d], min(d, lastc));
+    for (int c = 0; c < nchunks; c += DNS) {
+#pragma unroll
+        for (int d = 0; d < DNS; ++d) {
+            __syncthreads();
+            lstore(st[d]);
+            __syncthreads();
+            gload(st[d], min(c + d + DNS, lastc));
+            compute();
+        }
     }
 
-    float* out = g.out + (size_t)blockIdx.z * g.slab_stride;
+    float* out = g.out + (size_t)z * g.slab_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -403,12 +486,26 @@ int umlh_launch_to_bf16(const float* src, void* dst, long long n, hipStream_t st
     return (int)hipGetLastError();
 }
 
+int umlh_launch_iota(long long* dst, long long n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, n);
+    return (int)hipGetLastError();
+}
+
+int umlh_launch_w_shadow(const float* w, void* dst, int C, int K, int cpad, hipStream_t stream) {
+    long long total = (long long)(K / 16) * (cpad / 32) * 64;
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(w_shadow_kernel, dim3(blocks), dim3(256), 0, stream, w, (u16*)dst, C, K, cpad);
+    return (int)hipGetLastError();
+}
+
 // samples per block for a class-tile configuration (ctw, wc) and stw
 int umlh_bf16_fwd_ts(int wc, int stw) { return 32 * stw * (8 / wc); }
 
 static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
-    int ws = 8 / wc, cpad = 32 * ctw * wc, ts = 32 * stw * ws;
-    return (size_t)(cpad + ts) * RSB * 2 + sizeof(float) * (size_t)(8 * 32 * 4 + ws * 4 + 16);
+    int ws = 8 / wc, ts = 32 * stw * ws;
+    int xk = ws <= 2 ? 512 : (ws == 4 ? 256 : 128);
+    return (size_t)ts * (xk + 8) * 2 + sizeof(float) * (size_t)(8 * 32 * 4 + ws * 4 + 16);
 }
 
 #define FWDB_CASE(CT, W, S)                                                                          \
@@ -428,13 +525,14 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream) {
     if (grid <= 0) return 0;
     FWDB_CASE(1, 1, 1) FWDB_CASE(1, 2, 1) FWDB_CASE(1, 4, 1) FWDB_CASE(1, 8, 1) FWDB_CASE(2, 8, 1) FWDB_CASE(4, 8, 1)
-    FWDB_CASE(1, 8, 2) FWDB_CASE(2, 8, 2) FWDB_CASE(4, 8, 2)
+    FWDB_CASE(2, 8, 2) FWDB_CASE(4, 8, 2)
     return (int)hipErrorInvalidValue;
 }
 
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, hipStream_t stream) {
     if (g->M <= 0 || g->N <= 0) return 0;
-    dim3 grid((g->N + DBN - 1) / DBN, (g->M + DBM - 1) / DBM, splits);
+    if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
+    dim3 grid(((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits);
     hipLaunchKernelGGL(dw_bf16, grid, dim3(256), 0, stream, *g);
     return (int)hipGetLastError();
 }
