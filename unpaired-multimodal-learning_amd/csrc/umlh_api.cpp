@@ -18,6 +18,8 @@ int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStrea
 int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long long slab_stride, long long n,
                               float* grad_out, float* p, float* m, float* v, const OptArgs* o, hipStream_t stream);
 int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream);
+int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
+                          float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, hipStream_t stream);
 int umlh_launch_zero_shot(const float* feats, const int64_t* labels, long long n, int d, int C, float* w,
                           hipStream_t stream);
 int umlh_launch_to_bf16(const float* src, void* dst, long long n, hipStream_t stream);
@@ -32,7 +34,7 @@ struct SegDescB {
     const u16* feats; const int64_t* feat_index; const int64_t* labels; const int64_t* label_index;
     const float* scale_ptr; int rows, ld, col0, blk0; float w_over_rows;
 };
-struct FwdArgsB { SegDescB seg[2]; const u16* W; int C, K; u16* dzt; int crows; float* partials; int dbg; };
+struct FwdArgsB { SegDescB seg[2]; const u16* W; int C, K; u16* dzt; int crows; float* partials; int dbg; int learn; };
 struct DwArgsB {
     const u16* A; const u16* B; const int64_t* k_rows; int ldb; const u16* B2; const int64_t* k_rows2; int ldb2;
     float* out; const u16* zeros; int M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit; long long slab_stride;
@@ -115,6 +117,7 @@ struct umlh_handle_s {
     // state carried from umlh_grad_step to umlh_apply_update
     int last_rows_img, last_rows_txt;
     bool iota_ready;            // bf16: identity row-id table in the workspace initialised
+    bool shadow_fresh;          // bf16: the W shadow was written by the previous step's update kernel
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
     bool profiling;
 };
@@ -210,6 +213,7 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
     h->buf = *b;
     h->bound = true;
     h->iota_ready = false;
+    h->shadow_fresh = false;
     return UMLH_OK;
 }
 
@@ -360,7 +364,11 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         // rewritten w_head: load_state_dict, zero-shot init)
         const int cpad = 32 * h->ctw * h->wc;
         const int crows = (int)round_up(c.num_classes, 128);
-        HIPCHK(umlh_launch_w_shadow(h->buf.w_head, w16, c.num_classes, c.d_shared, cpad, st), "w_shadow");
+        // refreshed here unless the previous step of the same umlh_train_steps call just wrote it
+        // from its update kernel (between calls the caller may have rewritten w_head)
+        if (!h->shadow_fresh)
+            HIPCHK(umlh_launch_w_shadow(h->buf.w_head, w16, c.num_classes, c.d_shared, cpad, st), "w_shadow");
+        h->shadow_fresh = false;
         mark(h, 1, st);
         FwdArgsB fb;
         memset(&fb, 0, sizeof(fb));
@@ -382,6 +390,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         fb.dzt = want_grad ? dz16 : nullptr; fb.crows = crows;
         fb.partials = ws(h, L.partials);
         { const char* e = getenv("UMLH_DBG_FWD"); fb.dbg = e ? atoi(e) : 0; }
+        fb.learn = c.learnable_temp;
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
         mark(h, 2, st);
         *n_slabs_head = 0; *n_slabs_proj = 0;
@@ -540,24 +549,39 @@ static int check_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch
     return UMLH_OK;
 }
 
-int umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
-                    float* scalars_out, void* stream) {
-    int rc = check_step(h, img, txt, hy, "umlh_train_step");
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
+static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
+                           float* scalars_out, hipStream_t st, bool keep_shadow) {
     int sh = 0, sp = 0;
-    rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
+    int rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
     if (rc) return rc;
     OptArgs o = make_opt(h->cfg, *hy);
     FinalizeArgs f = make_finalize(h, img, txt, hy, true, scalars_out, true);
-    HIPCHK(umlh_launch_finalize(&f, st), "finalize");
-    HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, nullptr,
-                                     h->buf.w_head, h->buf.m_head, h->buf.v_head, &o, st), "update head");
+    const umlh_config_t& c = h->cfg;
+    if (c.d_shared % 8 == 0) {
+        // one launch: slab sum + optimizer + (bf16) next step's W shadow + scalars / logit scales
+        const bool bf = c.precision == UMLH_PREC_BF16;
+        HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, h->L.n_head, c.num_classes, c.d_shared, h->buf.w_head,
+                                     h->buf.m_head, h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr,
+                                     32 * h->ctw * h->wc, &f, st), "head step");
+        h->shadow_fresh = bf && keep_shadow;
+    } else {
+        HIPCHK(umlh_launch_finalize(&f, st), "finalize");
+        HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, nullptr,
+                                         h->buf.w_head, h->buf.m_head, h->buf.v_head, &o, st), "update head");
+    }
     if (sp > 0)
         HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj, nullptr,
                                          h->buf.w_proj, h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
     mark(h, 5, st);
     return UMLH_OK;
+}
+
+int umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
+                    float* scalars_out, void* stream) {
+    int rc = check_step(h, img, txt, hy, "umlh_train_step");
+    if (rc) return rc;
+    h->shadow_fresh = false;          // the caller may have rewritten w_head since the last call
+    return train_step_impl(h, img, txt, hy, scalars_out, (hipStream_t)stream, false);
 }
 
 int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_stream_t* txt, int32_t n_steps,
@@ -583,10 +607,15 @@ int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_strea
         }
         umlh_hyper_t hy;
         hy.lr = lr[k]; hy.step = first_step + k; hy.alpha = alpha; hy.img_alpha = img_alpha;
-        int rc = umlh_train_step(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy,
-                                 scalars_out ? scalars_out + (size_t)k * UMLH_N_SCALARS : nullptr, stream);
+        int rc = check_step(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy, "umlh_train_steps");
+        if (rc) return rc;
+        if (k == 0) h->shadow_fresh = false;
+        rc = train_step_impl(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy,
+                             scalars_out ? scalars_out + (size_t)k * UMLH_N_SCALARS : nullptr, (hipStream_t)stream,
+                             k + 1 < n_steps);
         if (rc) return rc;
     }
+    h->shadow_fresh = false;
     return UMLH_OK;
 }
 
@@ -596,6 +625,7 @@ int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t*
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     int sh = 0, sp = 0;
+    h->shadow_fresh = false;
     rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
     if (rc) return rc;
     OptArgs o = make_opt(h->cfg, *hy);
@@ -651,6 +681,7 @@ int umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* b, float* scalars_out, 
     memset(&hy, 0, sizeof(hy));
     hy.lr = 0; hy.step = 1; hy.alpha = 1.f; hy.img_alpha = 1.f;
     int sh = 0, sp = 0;
+    h->shadow_fresh = false;
     rc = forward_backward(h, b, nullptr, &hy, false, st, &sh, &sp);
     if (rc) return rc;
     FinalizeArgs f = make_finalize(h, b, nullptr, &hy, true, scalars_out, false);

@@ -15,6 +15,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 constexpr int KTB = 32;     // bf16 k elements staged per LDS chunk (two MFMA k-steps of 16)
 constexpr int RSB = 40;     // LDS row stride in shorts for k-contiguous tiles: 64 B data + 16 B pad
@@ -93,6 +95,7 @@ struct FwdArgsB {
     int   crows;                 // class rows per column chunk (C rounded up to 128)
     float* partials;
     int   dbg;                   // timing-only ablations: 1 = main loop only, 2 = epilogue only
+    int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
 };
 
 struct DwArgsB {
@@ -122,7 +125,11 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     constexpr int NPX = (TS * (XK / 8)) / 512;                   // 16-B pieces of the X block per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xt = reinterpret_cast<u16*>(smem_raw);                  // [TS][XRS]
-    float* red = reinterpret_cast<float*>(Xt + TS * XRS);        // [WS][WC][32][4]
+    constexpr int STAGE_BYTES = 8 * CTW * 32 * 64;               // dZ staging: 8 waves x [CTW*32 rows][64 B]
+    constexpr int XT_BYTES = TS * XRS * 2;
+    constexpr int UNION_BYTES = XT_BYTES > STAGE_BYTES ? XT_BYTES : STAGE_BYTES;
+    unsigned* dzstage = reinterpret_cast<unsigned*>(smem_raw);   // aliases Xt: used only after the last barrier of pass 2
+    float* red = reinterpret_cast<float*>(smem_raw + UNION_BYTES);   // [WS][WC][32][4]
     float* red2 = red + 8 * 32 * 4;                              // [WS][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,6 +149,15 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         int r = min(row0 + p / (XK / 8), sg.rows - 1);
         int64_t rid = sg.feat_index ? sg.feat_index[r] : (int64_t)r;
         xsrc[q] = sg.feats + (size_t)rid * sg.ld + 8 * (p % (XK / 8));
+    }
+
+    // labels of this lane's samples: two dependent global loads (row id, then label) issued NOW so
+    // their latency hides behind the whole main loop instead of stalling the epilogue
+    int labs[STW];
+#pragma unroll
+    for (int st = 0; st < STW; ++st) {
+        int r = min(row0 + ws * 32 * STW + st * 32 + l31, sg.rows - 1);
+        labs[st] = (int)sg.labels[sg.label_index ? sg.label_index[r] : (int64_t)r];
     }
 
     f32x16 acc[CTW][STW];
@@ -220,97 +236,142 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         return;
     }
     // ---------------- epilogue (per 32-sample tile of this wave) ----------------
+    // VALU-bound (64 logits per lane per tile): every pass is kept to a few ops per element --
+    // the max/argmax pass compares RAW accumulators (sign of the scale applied once), exp is one
+    // fma + v_exp_f32 (base-2, scale*log2e folded), dZ packs two columns per dword with a DPP swap
+    // and v_cvt_pk_bf16_f32, stores use a per-lane base + compile-time offsets.
     const float scale = *sg.scale_ptr;
+    const float sgn = scale < 0.f ? -1.f : 1.f;          // argmax(scale*raw) = argmax(sgn*raw)
+    const float LOG2E = 1.4426950408889634f;
+    const float sl2 = scale * LOG2E;
     const float NEG_INF = -__builtin_huge_valf();
+    const bool learn = a.learn != 0;
     float bl = 0.f, bc = 0.f, bg = 0.f;            // block sums: loss, correct, dscale
 #pragma unroll
     for (int st = 0; st < STW; ++st) {
         const int smp = ws * 32 * STW + st * 32 + l31;
         const int r = row0 + smp;
         const bool valid = r < sg.rows;
-        int lab = -1;
-        if (valid) lab = (int)sg.labels[sg.label_index ? sg.label_index[r] : (int64_t)r];
-        float mx = NEG_INF;
+        const int lab = valid ? labs[st] : -1;
+        // ---- pass 1: first arg-max of the (sign-corrected) raw logits ----
+        float mk = NEG_INF;
         int mi = 0x7fffffff;
 #pragma unroll
-        for (int ct = 0; ct < CTW; ++ct)
+        for (int ct = 0; ct < CTW; ++ct) {
+            const int cbase = (wc * CTW + ct) * 32;
+            const bool full = cbase + 32 <= C;           // wave-uniform
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
-                float v = cls < C ? acc[ct][st][i] * scale : NEG_INF;
-                if (v > mx) { mx = v; mi = cls; }
+                const int cls = cbase + acc_row(i, h);
+                float key = sgn > 0.f ? acc[ct][st][i] : -acc[ct][st][i];
+                if (!full) key = cls < C ? key : NEG_INF;
+                if (key > mk) { mk = key; mi = cls; }
             }
+        }
         {
-            float omx = __shfl_xor(mx, 32);
+            float omk = __shfl_xor(mk, 32);
             int omi = __shfl_xor(mi, 32);
-            if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+            if (omk > mk || (omk == mk && omi < mi)) { mk = omk; mi = omi; }
         }
         if (WC > 1) {
             __syncthreads();
-            if (h == 0) { red[((ws * WC + wc) * 32 + l31) * 4 + 0] = mx; red[((ws * WC + wc) * 32 + l31) * 4 + 1] = __int_as_float(mi); }
+            if (h == 0) { red[((ws * WC + wc) * 32 + l31) * 4 + 0] = mk; red[((ws * WC + wc) * 32 + l31) * 4 + 1] = __int_as_float(mi); }
             __syncthreads();
 #pragma unroll
             for (int w = 0; w < WC; ++w) {
-                float omx = red[((ws * WC + w) * 32 + l31) * 4 + 0];
+                float omk = red[((ws * WC + w) * 32 + l31) * 4 + 0];
                 int omi = __float_as_int(red[((ws * WC + w) * 32 + l31) * 4 + 1]);
-                if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+                if (omk > mk || (omk == mk && omi < mi)) { mk = omk; mi = omi; }
             }
         }
-        float se = 0.f, serw = 0.f, zy = 0.f, rawy = 0.f;
+        const float mx = mk * sgn * scale;               // max scaled logit ( = |scale| * mk )
+        const float mxl = mx * LOG2E;
+        // ---- pass 2: e = exp(z - max), sum, label logit ----
+        float se = 0.f, serw = 0.f, rawy = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < CTW; ++ct)
+        for (int ct = 0; ct < CTW; ++ct) {
+            const int cbase = (wc * CTW + ct) * 32;
+            const bool full = cbase + 32 <= C;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
-                float raw = acc[ct][st][i];
-                float e = cls < C ? __expf(raw * scale - mx) : 0.f;
+                const int cls = cbase + acc_row(i, h);
+                const float raw = acc[ct][st][i];
+                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(raw, sl2, -mxl));
+                if (!full) e = cls < C ? e : 0.f;
                 se += e;
-                serw += e * raw;
-                if (cls == lab) { zy = raw * scale; rawy = raw; }
+                if (learn) serw = __builtin_fmaf(e, raw, serw);
+                rawy = cls == lab ? raw : rawy;
                 acc[ct][st][i] = e;
             }
+        }
         se += __shfl_xor(se, 32);
         serw += __shfl_xor(serw, 32);
-        zy += __shfl_xor(zy, 32);
         rawy += __shfl_xor(rawy, 32);
         if (WC > 1) {
             __syncthreads();
             if (h == 0) {
                 float* d = red + ((ws * WC + wc) * 32 + l31) * 4;
-                d[0] = se; d[1] = serw; d[2] = zy; d[3] = rawy;
+                d[0] = se; d[1] = serw; d[2] = rawy;
             }
             __syncthreads();
-            se = serw = zy = rawy = 0.f;
+            se = serw = rawy = 0.f;
 #pragma unroll
             for (int w = 0; w < WC; ++w) {
                 const float* d = red + ((ws * WC + w) * 32 + l31) * 4;
-                se += d[0]; serw += d[1]; zy += d[2]; rawy += d[3];
+                se += d[0]; serw += d[1]; rawy += d[2];
             }
         }
+        const float zy = rawy * scale;
+        // ---- pass 3: dZ^T (bf16, two columns per dword) ----
         if (a.dzt != nullptr) {
-            // dZ^T[class][column] bf16.  Lanes l, l^1 hold neighbouring columns of the same class
-            // rows: swap one register of each pair so every lane stores ONE packed dword.
+            // Lanes l, l^1 hold neighbouring columns of the same class rows: each lane keeps one
+            // register of a pair, receives the neighbour's copy of it by a DPP quad swap and stores
+            // ONE packed dword (even lane: class row c0, odd lane: class row c0+1).
             const float coef = valid ? sg.w_over_rows * scale : 0.f;
-            const float inv = 1.f / se;
-            const int colpair = sg.col0 + row0 + (smp & ~1);
+            const float ic = coef / se;                   // dZ = e*ic - onehot*coef
             const bool odd = lane & 1;
+            // dword index of (class row = 4h + odd, this column pair) inside dZ^T's chunk-major layout
+            if (WC == 1 && st == 0) __syncthreads();       // staging aliases the X tile: every wave must have left the main loop
+            unsigned* dzs = dzstage + wave * (CTW * 32 * 16);                  // [CTW*32 rows][16 dwords]
+            const int lrow = lab - 4 * h - (odd ? 1 : 0);     // label relative to this lane's first row
 #pragma unroll
-            for (int ct = 0; ct < CTW; ++ct)
+            for (int ct = 0; ct < CTW; ++ct) {
+                const int cbase = (wc * CTW + ct) * 32;
+                const bool full = cbase + 32 <= C;
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
-                    int c0 = (wc * CTW + ct) * 32 + acc_row(i, h), c1 = c0 + 1;   // acc_row(i+1) = acc_row(i)+1 for even i
-                    float d0 = (acc[ct][st][i] * inv - (c0 == lab ? 1.f : 0.f)) * coef;
-                    float d1 = (acc[ct][st][i + 1] * inv - (c1 == lab ? 1.f : 0.f)) * coef;
-                    float send = odd ? d0 : d1;
-                    float recv = __shfl_xor(send, 1);
-                    // even lane: (own d0 @col, recv = neighbour's d0 @col+1) -> class c0
-                    // odd  lane: (recv = neighbour's d1 @col-1, own d1 @col) -> class c1
-                    unsigned packed = odd ? (f2bf(recv) | ((unsigned)f2bf(d1) << 16))
-                                          : (f2bf(d0) | ((unsigned)f2bf(recv) << 16));
-                    int cls = odd ? c1 : c0;
-                    if (cls < C)
-                        *reinterpret_cast<unsigned*>(a.dzt + ((size_t)(colpair >> 6) * a.crows + cls) * 64 + (colpair & 63)) = packed;
+                    const int rrow = cbase + (i & 3) + 8 * (i >> 2);          // class row of register i at h = 0, even lane
+                    // even lane keeps register i (row rrow+4h), odd lane keeps register i+1 (row rrow+4h+1)
+                    const float own_e = odd ? acc[ct][st][i + 1] : acc[ct][st][i];
+                    const float snd_e = odd ? acc[ct][st][i] : acc[ct][st][i + 1];
+                    // the neighbour needs MY value for ITS row: row of snd = rrow+4h+(odd?0:1)
+                    const int lab_s = lab - 4 * h - (odd ? 0 : 1);
+                    float own = __builtin_fmaf(own_e, ic, lrow == rrow ? -coef : 0.f);
+                    float snd = __builtin_fmaf(snd_e, ic, lab_s == rrow ? -coef : 0.f);
+                    // quad_perm [1,0,3,2]: swap with lane ^ 1
+                    float rcv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0xB1, 0xf, 0xf, true));
+                    bf16x2v pk = odd ? __builtin_convertvector(f32x2v{rcv, own}, bf16x2v)
+                                     : __builtin_convertvector(f32x2v{own, rcv}, bf16x2v);
+                    // stage in this wave's private LDS slice [class row][32 columns] (64-B rows)
+                    const int lr = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * h + (odd ? 1 : 0);   // row within the wave's CTW*32
+                    dzs[lr * 16 + (l31 >> 1)] = __builtin_bit_cast(unsigned, pk);
                 }
+            }
+            // wave-local transpose done (same wave wrote and reads: program order + lgkmcnt suffice).
+            // Each lane now stores 16 B = 8 columns of one class row: 16 rows x 64 B per instruction
+            // instead of 4-B scattered stores (the store tail was issue-bound, not bandwidth-bound).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int colbase = sg.col0 + row0 + ws * 32 * STW + st * 32;      // first column of this 32-sample tile
+            u16* gbase = a.dzt + ((size_t)(colbase >> 6) * a.crows) * 64 + (colbase & 63);
+#pragma unroll
+            for (int it = 0; it < CTW * 2; ++it) {
+                const int lr = it * 16 + (lane >> 2);                           // row within the wave's class range
+                const int cls = wc * CTW * 32 + lr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(dzs + lr * 16 + (lane & 3) * 4);
+                if (cls < C) *reinterpret_cast<u32x4*>(gbase + (size_t)cls * 64 + (lane & 3) * 8) = v;
+            }
         }
         if (wc == 0 && h == 0 && valid) {
             bl += __logf(se) + mx - zy;
@@ -505,7 +566,8 @@ int umlh_bf16_fwd_ts(int wc, int stw) { return 32 * stw * (8 / wc); }
 static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
     int ws = 8 / wc, ts = 32 * stw * ws;
     int xk = ws <= 2 ? 512 : (ws == 4 ? 256 : 128);
-    return (size_t)ts * (xk + 8) * 2 + sizeof(float) * (size_t)(8 * 32 * 4 + ws * 4 + 16);
+    size_t xt = (size_t)ts * (xk + 8) * 2, stage = (size_t)8 * ctw * 32 * 64;
+    return (xt > stage ? xt : stage) + sizeof(float) * (size_t)(8 * 32 * 4 + ws * 4 + 16);
 }
 
 #define FWDB_CASE(CT, W, S)                                                                          \

@@ -455,8 +455,7 @@ __global__ __launch_bounds__(256) void reduce_update(const float* __restrict__ s
 // --------------------------------------------------------------------------- //
 // per-step scalars + logit-scale parameters
 // --------------------------------------------------------------------------- //
-__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
-    __shared__ float sh[6][256];
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& f, float (*sh)[256]) {
     const int tid = threadIdx.x;
     if (f.partials != nullptr) {
         float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -495,6 +494,64 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
         float p = f.scales[tid], m = f.m_scales[tid], v = f.v_scales[tid];
         opt_update(f.opt, f.tail[tid], p, m, v);
         f.scales[tid] = p; f.m_scales[tid] = m; f.v_scales[tid] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
+    __shared__ float sh[6][256];
+    finalize_body(f, sh);
+}
+
+// --------------------------------------------------------------------------- //
+// head step: ONE launch for everything after the dW GEMM of a training step --
+// sum the split-K slabs, apply the optimizer to (W, m, v), refresh the bf16 fragment-major
+// shadow of W that the next forward streams (bf16 mode), and (last block) reduce the forward
+// partials to the step's scalars + update the learnable logit scales.
+// --------------------------------------------------------------------------- //
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
+}
+
+__global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+                                                        int C, int K, float* __restrict__ p, float* __restrict__ m,
+                                                        float* __restrict__ v, OptArgs o, unsigned short* __restrict__ shadow,
+                                                        int cpad, FinalizeArgs f) {
+    __shared__ float sh[6][256];
+    if (blockIdx.x == gridDim.x - 1) { finalize_body(f, sh); return; }
+    const long long g8 = (long long)blockIdx.x * 256 + threadIdx.x;      // group of 8 consecutive k of one class row
+    const long long n8 = (long long)C * K / 8;
+    if (g8 >= n8) return;
+    const long long i = g8 * 8;
+    f32x4v g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_slabs; ++s) {
+        const float* q = slabs + (size_t)s * slab_stride + i;
+        g0 += *reinterpret_cast<const f32x4v*>(q);
+        g1 += *reinterpret_cast<const f32x4v*>(q + 4);
+    }
+    f32x4v p0 = *reinterpret_cast<f32x4v*>(p + i), p1 = *reinterpret_cast<f32x4v*>(p + i + 4);
+    f32x4v m0 = *reinterpret_cast<f32x4v*>(m + i), m1 = *reinterpret_cast<f32x4v*>(m + i + 4);
+    f32x4v v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (o.kind != UMLH_OPT_SGD) { v0 = *reinterpret_cast<f32x4v*>(v + i); v1 = *reinterpret_cast<f32x4v*>(v + i + 4); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = p0[j], b = m0[j], c = v0[j];
+        opt_update(o, g0[j], a, b, c);
+        p0[j] = a; m0[j] = b; v0[j] = c;
+        a = p1[j]; b = m1[j]; c = v1[j];
+        opt_update(o, g1[j], a, b, c);
+        p1[j] = a; m1[j] = b; v1[j] = c;
+    }
+    *reinterpret_cast<f32x4v*>(p + i) = p0; *reinterpret_cast<f32x4v*>(p + i + 4) = p1;
+    *reinterpret_cast<f32x4v*>(m + i) = m0; *reinterpret_cast<f32x4v*>(m + i + 4) = m1;
+    if (o.kind != UMLH_OPT_SGD) { *reinterpret_cast<f32x4v*>(v + i) = v0; *reinterpret_cast<f32x4v*>(v + i + 4) = v1; }
+    if (shadow != nullptr) {
+        const int cls = (int)(i / K), k = (int)(i % K);
+        const long long piece = ((long long)(k >> 4) * (cpad / 32) + (cls >> 5)) * 64 + (cls & 31) + 32 * ((k >> 3) & 1);
+        u32x4s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3]), pack_bf16x2(p1[0], p1[1]), pack_bf16x2(p1[2], p1[3])};
+        *reinterpret_cast<u32x4s*>(shadow + piece * 8) = w;
     }
 }
 
@@ -595,6 +652,15 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
     else
         hipLaunchKernelGGL((reduce_update<1>), dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, n,
                            grad_out, p, m, v, *o);
+    return (int)hipGetLastError();
+}
+
+int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
+                          float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, hipStream_t stream) {
+    long long n8 = (long long)C * K / 8;
+    int blocks = (int)((n8 + 255) / 256) + 1;                 // + the finalize block
+    hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, *o,
+                       (unsigned short*)shadow, cpad, *f);
     return (int)hipGetLastError();
 }
 
