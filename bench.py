@@ -42,7 +42,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--precision", default=os.environ.get("UMLH_PRECISION", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("UMLH_PRECISION", "bf16"), choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE config 2 (headline); fp32 = exact-parity mode")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the additional fp32 parity-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--order-rng", default="device", choices=["device", "torch-cpu"],
                     help="epoch permutations drawn on the GPU (default) or by the reference-identical CPU sampler")
@@ -82,18 +84,47 @@ def main():
                                        order_rng=args.order_rng), dev, "image", args.precision)
     txt_src = _RowSource(FeatureLoader(FeatureTable(x_txt, y_txt, dev), BATCH, shuffle=True, kind="text",
                                        order_rng=args.order_rng), dev, "text", args.precision)
-    engine = model.fused_engine(optimizer, BATCH, BATCH, precision=args.precision)
-    stepper = umlh.DataParallelStepper(engine)
-    stepper.broadcast_parameters([model.head.weight.data])
-    scal = torch.zeros(args.warmup + args.steps + 64, umlh.N_SCALARS, device=dev)
+    scal = torch.zeros(2 * (args.warmup + args.steps) + 128, umlh.N_SCALARS, device=dev)
+    cursor = {"k": 0}
 
-    tab_i = img_src.table(args.precision)
-    tab_t = txt_src.table(args.precision)
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
 
-    def run_steps(k0, n):
-        """n steps through ONE umlh_train_steps call (N=1) or per-step DP stepping (N>1)."""
-        rows = 0
-        if world == 1:
+    def measure(precision, steps, warmup):
+        """W warm-up steps, then `steps` timed steps bracketed by barrier + synchronize."""
+        engine = model.fused_engine(optimizer, BATCH, BATCH, precision=precision)
+        stepper = umlh.DataParallelStepper(engine)
+        stepper.broadcast_parameters([model.head.weight.data])
+        tab_i, tab_t = img_src.table(precision), txt_src.table(precision)
+
+        engine.bind_tables(tab_i, tab_t)
+
+        def one_step():
+            ii, ti = img_src.next_index(), txt_src.next_index()
+            if world > 1:       # grad -> all-reduce -> update, lean host path
+                stepper.step_indexed(ii, ti, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1,
+                                     alpha=1.0, scalars_out=scal[cursor["k"]])
+            else:
+                engine.train_step(umlh.RowBatch(tab_i[0], tab_i[1], ii, feats_bf16=tab_i[2] if len(tab_i) > 2 else None),
+                                  umlh.RowBatch(tab_t[0], tab_t[1], ti, feats_bf16=tab_t[2] if len(tab_t) > 2 else None),
+                                  lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1, alpha=1.0,
+                                  scalars_out=scal[cursor["k"]])
+            cursor["k"] += 1
+            optimizer.step_count += 1
+            scheduler.step()
+            return int(ii.numel()) + int(ti.numel())
+
+        def run_steps(n):
+            """N=1: blocks of `--block` steps through ONE umlh_train_steps call each (the host prepares
+            the next block's index vectors while the GPU runs); N>1: per-step DP stepping."""
+            rows = 0
+            if world > 1:
+                for _ in range(n):
+                    rows += one_step()
+                return rows
             done = 0
             while done < n:
                 m = min(args.block, n - done)
@@ -102,62 +133,53 @@ def main():
                     bi.append(img_src.next_index())
                     bt.append(txt_src.next_index())
                 engine.train_steps(tab_i, bi, tab_t, bt, scheduler.lr_table(m), first_step=optimizer.step_count + 1,
-                                   alpha=1.0, scalars_out=scal[k0 + done:k0 + done + m])
+                                   alpha=1.0, scalars_out=scal[cursor["k"]:cursor["k"] + m])
+                cursor["k"] += m
                 optimizer.step_count += m
                 scheduler.step(scheduler.last_epoch + m)
                 rows += sum(int(b.numel()) for b in bi) + sum(int(b.numel()) for b in bt)
                 done += m
             return rows
-        for k in range(n):
-            rows += one_step(k0 + k)
-        return rows
 
-    def one_step(k):
-        bi, bt = img_src.next(), txt_src.next()
-        stepper.step(bi, bt, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1, alpha=1.0,
-                     scalars_out=scal[k])
-        optimizer.step_count += 1
-        scheduler.step()
-        return bi.n_rows() + bt.n_rows()
-
-    def fence():
-        torch.cuda.synchronize(dev)
+        run_steps(warmup)
+        fence()
+        t0 = time.perf_counter()
+        rows = run_steps(steps)
+        t_enq = time.perf_counter() - t0
+        fence()
+        dt = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    run_steps(0, args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    rows = run_steps(args.warmup, args.steps)
-    t_enq = time.perf_counter() - t0
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        r = torch.tensor([rows], device=dev, dtype=torch.float64)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rows = int(r.item())
-    value = rows / dt
-
-    # ---- roofline leg: per-kernel device time from HIP events on the step's stream ----
-    engine.profile(True)
-    acc, nprof = {}, 30
-    for k in range(nprof):
-        one_step(args.warmup + args.steps + k)
-        for name, ms in engine.profile_read().items():
-            acc[name] = acc.get(name, 0.0) + ms / nprof
-    engine.profile(False)
-    flops = {"fwd_ce": 2.0 * 2 * BATCH * C * D, "dw_head": 2.0 * 2 * BATCH * C * D}   # per launch, algorithmic
-    dom = max(("fwd_ce", "dw_head"), key=lambda n: acc[n])
-    achieved = flops[dom] / (acc[dom] * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[args.precision],
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.precision], 4), "traffic": None,
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            r = torch.tensor([rows], device=dev, dtype=torch.float64)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            rows = int(r.item())
+        final = scal[cursor["k"] - 1].cpu().tolist()
+        # roofline leg: per-kernel device time from HIP events recorded on the step's stream
+        engine.profile(True)
+        acc, nprof = {}, 30
+        for _ in range(nprof):
+            one_step()
+            for name, ms in engine.profile_read().items():
+                acc[name] = acc.get(name, 0.0) + ms / nprof
+        engine.profile(False)
+        flops = {"fwd_ce": 2.0 * 2 * BATCH * C * D, "dw_head": 2.0 * 2 * BATCH * C * D}   # algorithmic, per launch
+        dom = max(("fwd_ce", "dw_head"), key=lambda n: acc[n])
+        achieved = flops[dom] / (acc[dom] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[precision],
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK[precision], 4), "traffic": None,
                 "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
-                "step_frac_of_mfma_roof": round((sum(flops.values()) / (PEAK[args.precision] * 1e12)) / (dt / args.steps), 4)}
-    final = scal[args.warmup + args.steps - 1].cpu().tolist()
+                "step_frac_of_mfma_roof": round((sum(flops.values()) / (PEAK[precision] * 1e12)) / (dt / steps), 4)}
+        return {"value": rows / dt, "dt": dt, "rows": rows, "ms_per_step": dt / steps * 1e3,
+                "host_enqueue_ms_per_step": t_enq / steps * 1e3, "final": final, "roofline": roof}
+
+    head = measure(args.precision, args.steps, args.warmup)
+    other = None
+    if args.precision == "bf16" and not args.no_fp32_leg:
+        # the exact-parity fp32 mode on the same workload (fewer steps: it is ~4x slower)
+        other = measure("fp32", max(10, args.steps // 4), max(3, args.warmup // 4))
+    value, dt, roofline, final = head["value"], head["dt"], head["roofline"], head["final"]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -171,7 +193,7 @@ def main():
             cores = os.cpu_count() or 1
         # a 1-GPU box's CPU share is 16 cores; more torch threads than that only oversubscribes
         threads = min(cores, int(os.environ.get("UMLH_CPU_THREADS", 16)))
-        ncpu = int(os.environ.get("UMLH_CPU_STEPS", 12))
+        ncpu = int(os.environ.get("UMLH_CPU_STEPS", 150))
         v, secs, n = cpu_loop.reference_shaped_steps(xi, yi, xt, yt, C, BATCH, steps=ncpu, warmup=2, threads=threads)
         vb, _, _ = cpu_loop.bare_math_steps(xi, yi, xt, yt, C, BATCH, steps=ncpu, warmup=2, threads=threads)
         cpu = {"value": round(v, 1), "unit": "samples/s", "cores": threads, "kind": "port",
@@ -181,7 +203,7 @@ def main():
 
     if rank == 0:
         out = {"metric": METRIC, "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+               "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
                "data": "synthetic",
                "config": {"workload": "cfg2 ImageNet-1k CLIP-ViT-B/16 features (d=512) + unpaired CUPL text, linear head "
@@ -191,8 +213,11 @@ def main():
                           "parallelism": f"dp{world}", "precision_mode": args.precision, "order_rng": args.order_rng,
                           "steps_per_call": args.block},
                "final_loss": {"img": round(final[0], 4), "txt": round(final[1], 4)},
-               "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+               "host_enqueue_ms_per_step": round(head["host_enqueue_ms_per_step"], 4),
                "roofline": roofline, "cpu_baseline": cpu}
+        if other is not None:
+            out["fp32_parity_mode"] = {"value": round(other["value"], 1), "ms_per_step": round(other["ms_per_step"], 4),
+                                       "dtype": "f32", "roofline": other["roofline"]}
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)

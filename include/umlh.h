@@ -93,7 +93,13 @@ typedef struct {
     int64_t step;
     float   alpha;      /* weight of the text CE   (args.alpha)      finetune.py:188 */
     float   img_alpha;  /* weight of the image CE  (img_alpha = 1.0) finetune.py:160 */
+    int32_t flags;      /* UMLH_F_* */
+    int32_t reserved;
 } umlh_hyper_t;
+/* The caller guarantees that w_head has not been written by anyone but this handle since its
+ * last umlh_apply_update / umlh_train_step: the bf16 weight shadow the update kernel produced
+ * may be reused instead of rebuilt (bf16 mode only; default is to rebuild on every call). */
+#define UMLH_F_WEIGHTS_UNCHANGED 1
 
 /* Device float[UMLH_N_SCALARS] written by train/grad/eval calls. */
 #define UMLH_S_LOSS_IMG   0   /* mean CE over image rows   finetune.py:186 */

@@ -79,3 +79,58 @@ def test_two_ranks_one_gpu_matches_single_rank():
         assert (diff > 1e-6 + 1e-5 * np.abs(ref)).mean() < 1e-3 and diff.max() < 5e-3   # Adam sign flips at |g|~eps
         np.testing.assert_allclose(sc[:4], scal.cpu().numpy()[:4], atol=1e-5)
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def _worker_indexed(rank, world, port, q, precision):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "unpaired-multimodal-learning_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import umlh
+        rng = np.random.default_rng(8)
+        d, C, n = 128, 50, 256
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        y = rng.integers(0, C, n)
+        w = (rng.standard_normal((C, d)) * 0.1).astype(np.float32)
+        dev = "cuda:0"
+        e = umlh.HeadEngine(d, d, C, optimizer="sgd", weight_decay=0.0, max_rows_img=128, max_rows_txt=128,
+                            precision=precision, device=dev)
+        e.w_head.copy_(torch.from_numpy(w))
+        e.scales.fill_(20.0)
+        xt, yt = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+        tab = (xt, yt, umlh.to_bf16(xt)) if precision == "bf16" else (xt, yt)
+        e.bind_tables(tab, tab)
+        st = umlh.DataParallelStepper(e)
+        for k in range(3):     # rank r takes rows r::world of a fixed 128-row batch; weights_unchanged path after step 0
+            idx = torch.arange(rank + 64 * k, 64 * k + 128, world, device=dev)
+            st.step_indexed(idx, idx, lr=0.05, step=k + 1)
+        torch.cuda.synchronize()
+        q.put((rank, e.w_head.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_indexed_dp_path_two_ranks_vs_single(precision):
+    """Lean step_indexed path (bind_tables, shadow reuse between steps) on two ranks == one rank."""
+    import torch.multiprocessing as mp
+    res = {}
+    for world in (1, 2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker_indexed, args=(r, world, port, q, precision)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        res[world] = sorted(out, key=lambda t: t[0])
+    ref = res[1][0][1]
+    tol = 1e-6 if precision == "fp32" else 3e-3
+    for rank, w in res[2]:
+        np.testing.assert_allclose(w, ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)

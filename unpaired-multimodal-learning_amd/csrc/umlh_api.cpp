@@ -19,7 +19,7 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
                               float* grad_out, float* p, float* m, float* v, const OptArgs* o, hipStream_t stream);
 int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream);
 int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
-                          float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, hipStream_t stream);
+                          float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out, hipStream_t stream);
 int umlh_launch_zero_shot(const float* feats, const int64_t* labels, long long n, int d, int C, float* w,
                           hipStream_t stream);
 int umlh_launch_to_bf16(const float* src, void* dst, long long n, hipStream_t stream);
@@ -154,10 +154,10 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->ts = umlh_f32_fwd_config(cfg->num_classes, &h->ctw, &h->wc);
     h->stw = 1;
     if (cfg->precision == UMLH_PREC_BF16) {
-        // two 32-sample tiles per wave halve the L2->CU stream of the head weight (the bound of the
-        // forward kernel at C ~ 1000) once there are enough rows to keep >= 128 CUs busy
+        // two 32-sample tiles per wave would halve the L2->CU stream of the head weight, but measured
+        // slower on MI355X (51 vs 26 us at cfg2: half the CUs idle, VGPR-limited ring) -> opt-in only
         const char* e = getenv("UMLH_BF16_STW");
-        int want = e ? atoi(e) : ((cfg->max_rows_img + cfg->max_rows_txt) >= 4096 ? 2 : 1);
+        int want = e ? atoi(e) : 1;
         if (h->wc == 8 && h->ctw >= 2 && want == 2) h->stw = 2;
         h->ts = umlh_bf16_fwd_ts(h->wc, h->stw);
     }
@@ -562,7 +562,7 @@ static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_
         const bool bf = c.precision == UMLH_PREC_BF16;
         HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, h->L.n_head, c.num_classes, c.d_shared, h->buf.w_head,
                                      h->buf.m_head, h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr,
-                                     32 * h->ctw * h->wc, &f, st), "head step");
+                                     32 * h->ctw * h->wc, &f, nullptr, st), "head step");
         h->shadow_fresh = bf && keep_shadow;
     } else {
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
@@ -606,7 +606,7 @@ int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_strea
             bt.rows = bt.global_rows = txt->offsets[k + 1] - txt->offsets[k];
         }
         umlh_hyper_t hy;
-        hy.lr = lr[k]; hy.step = first_step + k; hy.alpha = alpha; hy.img_alpha = img_alpha;
+        hy.lr = lr[k]; hy.step = first_step + k; hy.alpha = alpha; hy.img_alpha = img_alpha; hy.flags = 0; hy.reserved = 0;
         int rc = check_step(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy, "umlh_train_steps");
         if (rc) return rc;
         if (k == 0) h->shadow_fresh = false;
@@ -625,15 +625,20 @@ int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t*
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     int sh = 0, sp = 0;
-    h->shadow_fresh = false;
+    if (!(hy->flags & UMLH_F_WEIGHTS_UNCHANGED)) h->shadow_fresh = false;
     rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
     if (rc) return rc;
     OptArgs o = make_opt(h->cfg, *hy);
     FinalizeArgs f = make_finalize(h, img, txt, hy, true, nullptr, false);
-    HIPCHK(umlh_launch_finalize(&f, st), "finalize");
     float* grads = ws(h, h->L.grads);
-    HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, grads, nullptr,
-                                     nullptr, nullptr, &o, st), "reduce head");
+    if (h->cfg.d_shared % 8 == 0) {
+        HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, h->L.n_head, h->cfg.num_classes, h->cfg.d_shared, nullptr,
+                                     nullptr, nullptr, &o, nullptr, 32 * h->ctw * h->wc, &f, grads, st), "reduce head");
+    } else {
+        HIPCHK(umlh_launch_finalize(&f, st), "finalize");
+        HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, grads, nullptr,
+                                         nullptr, nullptr, &o, st), "reduce head");
+    }
     if (h->cfg.has_proj) {
         if (sp > 0)
             HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj,
@@ -660,13 +665,21 @@ int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_ou
     hipStream_t st = (hipStream_t)stream;
     OptArgs o = make_opt(h->cfg, *hy);
     float* grads = ws(h, h->L.grads);
-    HIPCHK(umlh_launch_reduce_update(1, grads, 1, h->L.n_head, h->L.n_head, nullptr, h->buf.w_head, h->buf.m_head,
-                                     h->buf.v_head, &o, st), "update head");
+    FinalizeArgs f = make_finalize(h, nullptr, nullptr, hy, false, scalars_out, true);
+    if (h->cfg.d_shared % 8 == 0) {
+        const bool bf = h->cfg.precision == UMLH_PREC_BF16;
+        HIPCHK(umlh_launch_head_step(grads, 1, h->L.n_head, h->cfg.num_classes, h->cfg.d_shared, h->buf.w_head, h->buf.m_head,
+                                     h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr, 32 * h->ctw * h->wc, &f, nullptr,
+                                     st), "update head");
+        h->shadow_fresh = bf;              // the next umlh_grad_step may trust it (see umlh_grad_step)
+    } else {
+        HIPCHK(umlh_launch_reduce_update(1, grads, 1, h->L.n_head, h->L.n_head, nullptr, h->buf.w_head, h->buf.m_head,
+                                         h->buf.v_head, &o, st), "update head");
+        HIPCHK(umlh_launch_finalize(&f, st), "finalize");
+    }
     if (h->cfg.has_proj && h->last_rows_img > 0)
         HIPCHK(umlh_launch_reduce_update(1, grads + h->L.n_head, 1, h->L.n_proj, h->L.n_proj, nullptr, h->buf.w_proj,
                                          h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
-    FinalizeArgs f = make_finalize(h, nullptr, nullptr, hy, false, scalars_out, true);
-    HIPCHK(umlh_launch_finalize(&f, st), "finalize");
     return UMLH_OK;
 }
 

@@ -518,7 +518,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                         int C, int K, float* __restrict__ p, float* __restrict__ m,
                                                         float* __restrict__ v, OptArgs o, unsigned short* __restrict__ shadow,
-                                                        int cpad, FinalizeArgs f) {
+                                                        int cpad, FinalizeArgs f, float* __restrict__ grad_out) {
     __shared__ float sh[6][256];
     if (blockIdx.x == gridDim.x - 1) { finalize_body(f, sh); return; }
     const long long g8 = (long long)blockIdx.x * 256 + threadIdx.x;      // group of 8 consecutive k of one class row
@@ -530,6 +530,11 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
         const float* q = slabs + (size_t)s * slab_stride + i;
         g0 += *reinterpret_cast<const f32x4v*>(q);
         g1 += *reinterpret_cast<const f32x4v*>(q + 4);
+    }
+    if (grad_out != nullptr) {             // data-parallel split: gradient only, the update follows the all-reduce
+        *reinterpret_cast<f32x4v*>(grad_out + i) = g0;
+        *reinterpret_cast<f32x4v*>(grad_out + i + 4) = g1;
+        return;
     }
     f32x4v p0 = *reinterpret_cast<f32x4v*>(p + i), p1 = *reinterpret_cast<f32x4v*>(p + i + 4);
     f32x4v m0 = *reinterpret_cast<f32x4v*>(m + i), m1 = *reinterpret_cast<f32x4v*>(m + i + 4);
@@ -656,11 +661,12 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
 }
 
 int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
-                          float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, hipStream_t stream) {
+                          float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out,
+                          hipStream_t stream) {
     long long n8 = (long long)C * K / 8;
     int blocks = (int)((n8 + 255) / 256) + 1;                 // + the finalize block
     hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, *o,
-                       (unsigned short*)shadow, cpad, *f);
+                       (unsigned short*)shadow, cpad, *f, grad_out);
     return (int)hipGetLastError();
 }
 

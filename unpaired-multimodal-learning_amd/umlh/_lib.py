@@ -55,7 +55,8 @@ class Stream(C.Structure):
 
 
 class Hyper(C.Structure):
-    _fields_ = [("lr", C.c_double), ("step", C.c_int64), ("alpha", C.c_float), ("img_alpha", C.c_float)]
+    _fields_ = [("lr", C.c_double), ("step", C.c_int64), ("alpha", C.c_float), ("img_alpha", C.c_float),
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 def lib_path() -> str:

@@ -29,6 +29,12 @@ class DataParallelStepper:
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self._own_weights = False      # True once this stepper performed the last write of the weights
+        self._flat = None
+
+    def invalidate(self) -> None:
+        """Call after writing the parameters from outside (load_state_dict, re-init)."""
+        self._own_weights = False
 
     def broadcast_parameters(self, tensors, src: int = 0) -> None:
         if self.world > 1:
@@ -45,6 +51,27 @@ class DataParallelStepper:
         if self.world == 1:
             return self.engine.train_step(img, txt, lr=lr, step=step, alpha=alpha, img_alpha=img_alpha,
                                           scalars_out=scalars_out)
-        flat = self.engine.grad_step(self._with_global(img), self._with_global(txt), alpha=alpha, img_alpha=img_alpha)
+        try:
+            flat = self.engine.grad_step(self._with_global(img), self._with_global(txt), alpha=alpha, img_alpha=img_alpha,
+                                         weights_unchanged=self._own_weights)
+        except TypeError:              # engines without the hint (test doubles)
+            flat = self.engine.grad_step(self._with_global(img), self._with_global(txt), alpha=alpha, img_alpha=img_alpha)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        return self.engine.apply_update(lr=lr, step=step, scalars_out=scalars_out)
+        out = self.engine.apply_update(lr=lr, step=step, scalars_out=scalars_out)
+        self._own_weights = True
+        return out
+
+    def step_indexed(self, idx_img, idx_txt, lr: float, step: int, alpha: float = 1.0, img_alpha: float = 1.0,
+                     scalars_out=None, global_img=None, global_txt=None):
+        """Lean variant for device-resident tables registered with ``engine.bind_tables``: per step only
+        two index vectors change.  Equal shards assumed unless the global row counts are given."""
+        gi = global_img if global_img is not None else (idx_img.numel() * self.world if idx_img is not None else 0)
+        gt = global_txt if global_txt is not None else (idx_txt.numel() * self.world if idx_txt is not None else 0)
+        if self._flat is None:
+            self._flat = self.engine.grad_buffer()
+        self.engine.grad_step_indexed(idx_img, idx_txt, gi, gt, alpha, img_alpha, weights_unchanged=self._own_weights)
+        if self.world > 1:
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        out = self.engine.apply_update(lr=lr, step=step, scalars_out=scalars_out)
+        self._own_weights = True
+        return out

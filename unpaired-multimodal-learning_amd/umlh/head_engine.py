@@ -171,7 +171,7 @@ class HeadEngine:
     def train_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], lr: float, step: int,
                    alpha: float = 1.0, img_alpha: float = 1.0, scalars_out: Optional[torch.Tensor] = None):
         bi, bt = self._batch(img, self.d_img), self._batch(txt, self.d_shared)
-        hy = Hyper(float(lr), int(step), float(alpha), float(img_alpha))
+        hy = Hyper(float(lr), int(step), float(alpha), float(img_alpha), 0, 0)
         so = scalars_out if scalars_out is not None else self._scalars
         check(self.lib.umlh_train_step(self.handle, self._ref(bi), self._ref(bt), C.byref(hy), _ptr(so),
                                        self._stream()), "umlh_train_step")
@@ -218,12 +218,40 @@ class HeadEngine:
         self._keepalive = (keep_i, keep_t)
 
     def grad_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], alpha: float = 1.0,
-                  img_alpha: float = 1.0) -> torch.Tensor:
+                  img_alpha: float = 1.0, weights_unchanged: bool = False) -> torch.Tensor:
+        """``weights_unchanged=True``: the caller guarantees nobody but this engine wrote w_head since its
+        last apply_update/train_step (lets a bf16 engine reuse the weight shadow its update kernel wrote)."""
         bi, bt = self._batch(img, self.d_img), self._batch(txt, self.d_shared)
-        hy = Hyper(0.0, 1, float(alpha), float(img_alpha))
+        hy = Hyper(0.0, 1, float(alpha), float(img_alpha), 1 if weights_unchanged else 0, 0)
         check(self.lib.umlh_grad_step(self.handle, self._ref(bi), self._ref(bt), C.byref(hy), self._stream()),
               "umlh_grad_step")
         return self.grad_buffer()
+
+    # -- lean per-step path for the data-parallel loop (no per-step validation / object churn) ----
+    def bind_tables(self, img_table, txt_table) -> None:
+        """Validate the device-resident tables once and cache their ctypes descriptors;
+        afterwards ``grad_step_indexed`` only patches the index pointer and row counts."""
+        def mk(tab, dim):
+            if tab is None:
+                return None
+            rb = RowBatch(tab[0], tab[1], None, rows=1, feats_bf16=tab[2] if len(tab) > 2 else None)
+            b = self._batch(rb, dim)
+            b.keep = tab                      # keep the tensors alive
+            return b
+        self._tab = (mk(img_table, self.d_img), mk(txt_table, self.d_shared))
+        self._hy = Hyper(0.0, 1, 1.0, 1.0, 0, 0)
+
+    def grad_step_indexed(self, idx_img, idx_txt, global_img: int, global_txt: int, alpha: float = 1.0,
+                          img_alpha: float = 1.0, weights_unchanged: bool = False) -> None:
+        bi, bt = self._tab
+        if bi is not None:
+            bi.index, bi.rows, bi.global_rows = idx_img.data_ptr(), idx_img.numel(), global_img
+        if bt is not None:
+            bt.index, bt.rows, bt.global_rows = idx_txt.data_ptr(), idx_txt.numel(), global_txt
+        hy = self._hy
+        hy.alpha, hy.img_alpha, hy.flags = alpha, img_alpha, 1 if weights_unchanged else 0
+        check(self.lib.umlh_grad_step(self.handle, self._ref(bi), self._ref(bt), C.byref(hy), self._stream()),
+              "umlh_grad_step")
 
     def grad_buffer(self) -> torch.Tensor:
         """Flat fp32 view [g_head | g_proj | g_scales(2) | scalars(8)] inside the workspace."""
@@ -233,7 +261,7 @@ class HeadEngine:
         return self.workspace[off:off + n.value]
 
     def apply_update(self, lr: float, step: int, scalars_out: Optional[torch.Tensor] = None):
-        hy = Hyper(float(lr), int(step), 1.0, 1.0)
+        hy = Hyper(float(lr), int(step), 1.0, 1.0, 0, 0)
         so = scalars_out if scalars_out is not None else self._scalars
         check(self.lib.umlh_apply_update(self.handle, C.byref(hy), _ptr(so), self._stream()), "umlh_apply_update")
         return so
