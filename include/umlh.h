@@ -191,6 +191,20 @@ int  umlh_profile_read(umlh_handle_t h, float* ms_out /* host float[UMLH_N_PHASE
  * device-resident feature table once, for UMLH_PREC_BF16 handles. */
 int  umlh_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
 
+/* MultiBench alternation step (MultiBench/train.py:354-399, models.py:194-243): per-modality
+ * decoder Linear(z -> D) fused with the masked next-step MSE, forward and backward.
+ *   recon[b,t,:] = W z[b,t,:] + bias;  loss = sum_{t<T-1, t+1<len_b} |recon[b,t]-x[b,t+1]|^2 / (D*#live + 1e-8)
+ * (T == 1: plain reconstruction MSE, models.py:209-210; lengths == NULL: unmasked mean).
+ * z [B,T,Z], w [D,Z], bias [D], x [B,T,D] fp32 device; lengths int64[B] device or NULL.
+ * recon [B,T,D] optional; dres [B*T*D] and row_partial [B*T] scratch that the backward reads;
+ * loss_cnt device float[2] = {loss, denominator}.  Backward: grad_out device scalar (d/d loss);
+ * dz [B,T,Z], dw [D,Z], db [D]. */
+int  umlh_seq_mse_forward(const float* z, const float* w, const float* bias, const float* x, const int64_t* lengths,
+                          int32_t B, int32_t T, int32_t Z, int32_t D, float* recon, float* dres, float* row_partial,
+                          float* loss_cnt, void* stream);
+int  umlh_seq_mse_backward(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out,
+                           int32_t B, int32_t T, int32_t Z, int32_t D, float* dz, float* dw, float* db, void* stream);
+
 /* Standalone optimizer.step() for one parameter tensor from a caller-computed
  * gradient (engine/optimizer/optim.py:34-71; torch.optim single-tensor recurrences):
  * the same update kernel the fused step applies.  v may be NULL for SGD. */

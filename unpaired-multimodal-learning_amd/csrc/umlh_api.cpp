@@ -335,6 +335,30 @@ int umlh_optimizer_step(int32_t optimizer, float* param, const float* grad, floa
     return UMLH_OK;
 }
 
+extern "C" {
+int umlh_seq_launch_fwd(const float* z, const float* w, const float* b, const float* x, const int64_t* lengths, int B, int T,
+                        int Z, int D, float* recon, float* dres, float* row_partial, float* loss_cnt, hipStream_t st);
+int umlh_seq_launch_bwd(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out, int B,
+                        int T, int Z, int D, float* dz, float* dw, float* db, hipStream_t st);
+}
+
+int umlh_seq_mse_forward(const float* z, const float* w, const float* bias, const float* x, const int64_t* lengths, int32_t B,
+                         int32_t T, int32_t Z, int32_t D, float* recon, float* dres, float* row_partial, float* loss_cnt,
+                         void* stream) {
+    if (!z || !w || !bias || !x || !dres || !row_partial || !loss_cnt) return fail(UMLH_E_INVALID, "umlh_seq_mse_forward: null buffer");
+    if (B < 1 || T < 1 || Z < 1 || D < 1 || Z > 8192) return fail(UMLH_E_INVALID, "umlh_seq_mse_forward: bad shape B=%d T=%d Z=%d D=%d", B, T, Z, D);
+    HIPCHK(umlh_seq_launch_fwd(z, w, bias, x, lengths, B, T, Z, D, recon, dres, row_partial, loss_cnt, (hipStream_t)stream), "seq fwd");
+    return UMLH_OK;
+}
+
+int umlh_seq_mse_backward(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out,
+                          int32_t B, int32_t T, int32_t Z, int32_t D, float* dz, float* dw, float* db, void* stream) {
+    if (!z || !w || !dres || !loss_cnt || !grad_out || !dz || !dw || !db) return fail(UMLH_E_INVALID, "umlh_seq_mse_backward: null buffer");
+    if (B < 1 || T < 1 || Z < 1 || D < 1 || D > 8192) return fail(UMLH_E_INVALID, "umlh_seq_mse_backward: bad shape");
+    HIPCHK(umlh_seq_launch_bwd(z, w, dres, loss_cnt, grad_out, B, T, Z, D, dz, dw, db, (hipStream_t)stream), "seq bwd");
+    return UMLH_OK;
+}
+
 int umlh_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
     if (!src || !dst || n < 0) return fail(UMLH_E_INVALID, "umlh_to_bf16: bad arguments");
     HIPCHK(umlh_launch_to_bf16(src, dst, n, (hipStream_t)stream), "to_bf16");

@@ -1,0 +1,196 @@
+"""MultiBench UML model: per-modality Linear in/out projections around a shared causal
+transformer encoder, next-step prediction loss (reference: MultiBench/models.py:7-277,
+assembly MultiBench/main.py:117-121)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class Linear(nn.Module):
+    """nn.Linear wrapper with optional Xavier init and zero bias (models.py:7-35)."""
+
+    def __init__(self, indim, outdim, xavier_init=False):
+        super().__init__()
+        self.fc = nn.Linear(indim, outdim)
+        if xavier_init:
+            nn.init.xavier_normal_(self.fc.weight)
+            self.fc.bias.data.fill_(0.0)
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+class Transformer(nn.Module):
+    """Shared encoder: 1x1 conv (no bias) -> optional positions -> causal TransformerEncoder with
+    key-padding mask (models.py:39-127).  Third-party torch.nn arithmetic, kept on PyTorch-ROCm."""
+
+    def __init__(self, n_features, dim, nhead=5, num_layers=5, conv1d=True, out_last=True, pos_embd=False,
+                 pos_learnable=False, max_len=128):
+        super().__init__()
+        self.embed_dim, self.conv1d, self.out_last = dim, conv1d, out_last
+        self.pos_embd, self.pos_learnable, self.max_len = pos_embd, pos_learnable, max_len
+        if conv1d:
+            self.conv = nn.Conv1d(n_features, dim, kernel_size=1, padding=0, bias=False)
+        self.transformer = nn.TransformerEncoder(nn.TransformerEncoderLayer(d_model=dim, nhead=nhead), num_layers=num_layers)
+        if pos_embd:
+            if pos_learnable:
+                self.pos_embedding = nn.Embedding(max_len, dim)
+            else:
+                pos = torch.arange(max_len).unsqueeze(1)
+                div = torch.exp(torch.arange(0, dim, 2) * (-math.log(10000.0) / dim))
+                table = torch.zeros(max_len, dim)
+                table[:, 0::2] = torch.sin(pos * div)
+                table[:, 1::2] = torch.cos(pos * div)
+                self.register_buffer("pos_table", table)
+
+    def forward(self, x, lengths=None):
+        if type(x) is list:
+            x = x[0]
+        batch, seq_len, _ = x.shape
+        pad = None
+        if lengths is not None:
+            pad = torch.arange(seq_len, device=x.device).expand(batch, seq_len) >= lengths.unsqueeze(1)
+        x = self.conv(x.permute(0, 2, 1)).permute(2, 0, 1) if self.conv1d else x.permute(1, 0, 2)   # (T, B, D)
+        if self.pos_embd:
+            if x.size(0) > self.max_len:
+                x = x[:self.max_len]
+            idx = torch.arange(x.size(0), device=x.device)
+            pos = self.pos_embedding(idx) if self.pos_learnable else self.pos_table[idx]
+            x = x + pos.unsqueeze(1)
+        causal = torch.nn.Transformer.generate_square_subsequent_mask(x.size(0), device=x.device)
+        x = self.transformer(x, mask=causal, src_key_padding_mask=pad, is_causal=True)
+        if self.out_last:
+            if lengths is not None:
+                x = x.permute(1, 0, 2)
+                return x[torch.arange(batch, device=x.device), lengths - 1, :]
+            return x[-1]
+        return x.permute(1, 0, 2)
+
+
+class MSE(nn.Module):
+    """Masked mean squared error (models.py:129-143) -- torch-op form, used for shapes the fused
+    decoder kernel does not cover."""
+
+    def forward(self, predictions, targets, mask=None):
+        if mask is None:
+            return (predictions - targets).pow(2).mean()
+        m = mask.unsqueeze(-1).expand_as(targets).float()
+        return ((predictions - targets) ** 2 * m).sum() / (m.sum() + 1e-8)
+
+
+class SequenceInfoNCELoss(nn.Module):
+    """Contrastive alternative to the MSE critic (models.py:145-175); torch ops."""
+
+    def __init__(self, temperature=0.07):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, predictions, targets, mask=None):
+        if mask is not None:
+            p, t = predictions[mask.bool()], targets[mask.bool()]
+        else:
+            p, t = predictions.flatten(0, 1), targets.flatten(0, 1)
+        logits = F.normalize(p, dim=-1) @ F.normalize(t, dim=-1).T / self.temperature
+        return F.cross_entropy(logits, torch.arange(logits.shape[0], device=logits.device))
+
+
+class _DecoderNextStepMSE(torch.autograd.Function):
+    """recon = Linear(z); loss = masked MSE(recon[:, :-1], x[:, 1:])  -- one HIP forward + one HIP
+    backward (umlh_seq_mse_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, z, w, b, x, lengths):
+        import umlh
+        lib = umlh.load_library()
+        B, T, Z = z.shape
+        D = w.shape[0]
+        z, w, b, x = (t.detach().to(torch.float32).contiguous() for t in (z, w, b, x))
+        lens = None if lengths is None else lengths.to(device=z.device, dtype=torch.int64).contiguous()
+        recon = torch.empty(B, T, D, dtype=torch.float32, device=z.device)
+        dres = torch.empty(B * T * D, dtype=torch.float32, device=z.device)
+        part = torch.empty(B * T, dtype=torch.float32, device=z.device)
+        loss_cnt = torch.empty(2, dtype=torch.float32, device=z.device)
+        st = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        umlh._lib.check(lib.umlh_seq_mse_forward(p(z), p(w), p(b), p(x), p(lens), B, T, Z, D, p(recon), p(dres), p(part),
+                                                 p(loss_cnt), st), "umlh_seq_mse_forward")
+        ctx.save_for_backward(z, w, dres, loss_cnt)
+        ctx.shape = (B, T, Z, D)
+        ctx.mark_non_differentiable(recon)
+        return loss_cnt[0].clone(), recon
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_recon):
+        import umlh
+        lib = umlh.load_library()
+        z, w, dres, loss_cnt = ctx.saved_tensors
+        B, T, Z, D = ctx.shape
+        g = g_loss.detach().to(torch.float32).reshape(1).contiguous()
+        dz = torch.empty(B, T, Z, dtype=torch.float32, device=z.device)
+        dw = torch.empty(D, Z, dtype=torch.float32, device=z.device)
+        db = torch.empty(D, dtype=torch.float32, device=z.device)
+        st = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        umlh._lib.check(lib.umlh_seq_mse_backward(p(z), p(w), p(dres), p(loss_cnt), p(g), B, T, Z, D, p(dz), p(dw), p(db), st),
+                        "umlh_seq_mse_backward")
+        return dz, dw, db, None, None
+
+
+class UML(nn.Module):
+    """x -> xproj_in -> shared encoder -> decoders[0] -> next-step loss; same for y with decoders[1]
+    (models.py:178-277).  forward returns the reference's dict."""
+
+    def __init__(self, xproj_in, yproj_in, shared_encoder, decoders, modality="x", infoNCE_loss=False):
+        super().__init__()
+        self.xproj_in, self.yproj_in, self.encoder = xproj_in, yproj_in, shared_encoder
+        self.decoders = nn.ModuleList(decoders)
+        self.modality = modality
+        self.critic = MSE()
+        self.infoNCE_loss = infoNCE_loss
+        self.y_critic = SequenceInfoNCELoss() if infoNCE_loss else MSE()
+
+    def _branch(self, x, proj, dec, lengths, enc_lengths, use_nce):
+        x = x.unsqueeze(1).float() if x.ndim == 2 else x
+        x_proj = proj(x)
+        z = self.encoder(x_proj, lengths=enc_lengths)
+        if use_nce and x.shape[1] > 1:
+            recon = dec(z)
+            mask = None
+            if lengths is not None:
+                mask = torch.arange(x.shape[1], device=x.device).unsqueeze(0) < lengths.unsqueeze(1)
+            loss = self.y_critic(recon[:, :-1, :], x[:, 1:, :], mask=mask[:, 1:] if mask is not None else None)
+        else:
+            loss, recon = _DecoderNextStepMSE.apply(z, dec.fc.weight, dec.fc.bias, x, lengths)
+        diff_next = (x_proj - z).pow(2).mean()
+        return x, x_proj, z, recon, loss, diff_next
+
+    def forward(self, x, y, x_lengths=None, y_lengths=None):
+        dev = (x if x is not None else y).device
+        loss_x = loss_y = torch.tensor(0.0, device=dev)
+        x_proj = y_proj = zx = zy = x_recon = y_recon = diff_next_x = diff_next_y = None
+        if x is not None:
+            x, x_proj, zx, x_recon, loss_x, diff_next_x = self._branch(x, self.xproj_in, self.decoders[0], x_lengths,
+                                                                        x_lengths, False)
+        if y is not None:
+            # the reference encodes y WITHOUT a key-padding mask (models.py:233) but masks its loss
+            y, y_proj, zy, y_recon, loss_y, diff_next_y = self._branch(y, self.yproj_in, self.decoders[1], y_lengths,
+                                                                        None, self.infoNCE_loss)
+        loss_private = torch.tensor(0.0, device=dev)
+        x_private = y_private = None
+        if x is not None and y is not None:
+            x_private, y_private = x_proj - zx, y_proj - zy
+            if x_private.shape == y_private.shape:
+                loss_private = ((x_private * y_private).mean([1, 2]) ** 2).sum()
+        return {"loss_x": loss_x, "loss_y": loss_y, "loss_private": loss_private, "x_proj": x_proj, "y_proj": y_proj,
+                "zx": zx, "zy": zy, "x_recon": x_recon, "y_recon": y_recon, "x_private": x_private, "y_private": y_private,
+                "diff_next_x": diff_next_x, "diff_next_y": diff_next_y}
+
+    def get_embedding(self, x, y):
+        x = x.unsqueeze(1).float() if x.ndim == 2 else x
+        y = y.unsqueeze(1).float() if y.ndim == 2 else y
+        return self.encoder(self.xproj_in(x)).mean(dim=1), self.encoder(self.yproj_in(y)).mean(dim=1)

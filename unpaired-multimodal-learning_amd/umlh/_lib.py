@@ -18,12 +18,12 @@ PREC_IDS = {"fp32": 0, "bf16": 1}
 (S_LOSS_IMG, S_LOSS_TXT, S_ACC_IMG, S_ACC_TXT, S_GSCALE_IMG, S_GSCALE_TXT, S_CORRECT, S_LOSS_SUM) = range(8)
 N_SCALARS = 8
 
-SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_api.cpp"]
+SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_seq.hip", "umlh_api.cpp"]
 EXPORTS = ["umlh_last_error", "umlh_version", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
-           "umlh_train_steps"]
+           "umlh_train_steps", "umlh_seq_mse_forward", "umlh_seq_mse_backward"]
 
 
 class UmlhError(RuntimeError):
@@ -117,6 +117,8 @@ def load_library():
     lib.umlh_to_bf16.argtypes = [vp, vp, i64, vp]
     lib.umlh_train_steps.argtypes = [vp, C.POINTER(Stream), C.POINTER(Stream), i32, C.POINTER(C.c_double), i64,
                                      C.c_float, C.c_float, vp, vp]
+    lib.umlh_seq_mse_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.umlh_seq_mse_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.umlh_profile_enable.argtypes = [vp, C.c_int]
     lib.umlh_profile_read.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:
