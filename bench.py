@@ -167,8 +167,15 @@ def main():
         flops = {"fwd_ce": 2.0 * 2 * BATCH * C * D, "dw_head": 2.0 * 2 * BATCH * C * D}   # algorithmic, per launch
         dom = max(("fwd_ce", "dw_head"), key=lambda n: acc[n])
         achieved = flops[dom] / (acc[dom] * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file's note)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bf16_pmc.json")))["kernels"]
+            if precision == "bf16":
+                traffic = pmc[{"fwd_ce": "fwd_ce_bf16", "dw_head": "dw_bf16"}[dom]]["hbm_bytes_corrected"]
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[precision],
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK[precision], 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK[precision], 4), "traffic": traffic,
                 "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
                 "step_frac_of_mfma_roof": round((sum(flops.values()) / (PEAK[precision] * 1e12)) / (dt / steps), 4)}
         return {"value": rows / dt, "dt": dt, "rows": rows, "ms_per_step": dt / steps * 1e3,

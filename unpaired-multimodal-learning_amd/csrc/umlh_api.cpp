@@ -217,6 +217,18 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
     return UMLH_OK;
 }
 
+// forward blocks of the image segment: in bf16 mode the image columns of dZ^T are padded to whole
+// 64-column chunks (every dW chunk then lies in one modality); the padding tile(s) run with all rows
+// masked and write zeros
+static inline int fwd_blocks_img(const umlh_handle_s* h, int rows) {
+    int nb = (rows + h->ts - 1) / h->ts;
+    if (h->cfg.precision == UMLH_PREC_BF16 && h->ts < 64 && nb > 0) {
+        int per = 64 / h->ts;
+        nb = (nb + per - 1) / per * per;
+    }
+    return nb;
+}
+
 static inline float* ws(umlh_handle_t h, long long off) { return static_cast<float*>(h->buf.workspace) + off; }
 
 static int check_batch(umlh_handle_t h, const umlh_batch_t* b, int cap, const char* who) {
@@ -373,7 +385,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     const Layout& L = h->L;
     const int ri = img ? img->rows : 0, rt = txt ? txt->rows : 0;
     const int TS = h->ts;
-    const int nb0 = (ri + TS - 1) / TS, nb1 = (rt + TS - 1) / TS;
+    const int nb0 = fwd_blocks_img(h, ri), nb1 = (rt + TS - 1) / TS;
     const int r0p = nb0 * TS, r1p = nb1 * TS;
     float* H = ws(h, L.h);
     float* dzt = ws(h, L.dzt);
@@ -545,7 +557,7 @@ static FinalizeArgs make_finalize(umlh_handle_t h, const umlh_batch_t* img, cons
     FinalizeArgs f;
     memset(&f, 0, sizeof(f));
     f.partials = from_partials ? ws(h, h->L.partials) : nullptr;
-    f.nb0 = (ri + h->ts - 1) / h->ts;
+    f.nb0 = fwd_blocks_img(h, ri);
     f.nb1 = (rt + h->ts - 1) / h->ts;
     f.inv_rows0 = (img && img->rows > 0) ? 1.f / (float)img->global_rows : 0.f;
     f.inv_rows1 = (txt && txt->rows > 0) ? 1.f / (float)txt->global_rows : 0.f;

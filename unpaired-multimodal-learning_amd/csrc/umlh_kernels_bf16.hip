@@ -254,20 +254,29 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         const bool valid = r < sg.rows;
         const int lab = valid ? labs[st] : -1;
         // ---- pass 1: first arg-max of the (sign-corrected) raw logits ----
-        float mk = NEG_INF;
-        int mi = 0x7fffffff;
+        // one independent (max, index) chain per class tile: a single 64-long dependent chain would be
+        // latency-bound with only two waves per SIMD
+        float mkc[CTW];
+        int mic[CTW];
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct) {
             const int cbase = (wc * CTW + ct) * 32;
             const bool full = cbase + 32 <= C;           // wave-uniform
+            mkc[ct] = NEG_INF;
+            mic[ct] = 0x7fffffff;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int cls = cbase + acc_row(i, h);
                 float key = sgn > 0.f ? acc[ct][st][i] : -acc[ct][st][i];
                 if (!full) key = cls < C ? key : NEG_INF;
-                if (key > mk) { mk = key; mi = cls; }
+                if (key > mkc[ct]) { mkc[ct] = key; mic[ct] = cls; }
             }
         }
+        float mk = mkc[0];
+        int mi = mic[0];
+#pragma unroll
+        for (int ct = 1; ct < CTW; ++ct)                 // ascending class order: strict > keeps the first
+            if (mkc[ct] > mk) { mk = mkc[ct]; mi = mic[ct]; }
         {
             float omk = __shfl_xor(mk, 32);
             int omi = __shfl_xor(mi, 32);
@@ -284,26 +293,31 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
                 if (omk > mk || (omk == mk && omi < mi)) { mk = omk; mi = omi; }
             }
         }
+        if (a.dbg == 4) { bl += mk; continue; }          // ablation: argmax pass only
         const float mx = mk * sgn * scale;               // max scaled logit ( = |scale| * mk )
         const float mxl = mx * LOG2E;
         // ---- pass 2: e = exp(z - max), sum, label logit ----
-        float se = 0.f, serw = 0.f, rawy = 0.f;
+        float sec[CTW], serwc[CTW], rawyc[CTW];
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct) {
             const int cbase = (wc * CTW + ct) * 32;
             const bool full = cbase + 32 <= C;
+            sec[ct] = serwc[ct] = rawyc[ct] = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int cls = cbase + acc_row(i, h);
                 const float raw = acc[ct][st][i];
                 float e = __builtin_amdgcn_exp2f(__builtin_fmaf(raw, sl2, -mxl));
                 if (!full) e = cls < C ? e : 0.f;
-                se += e;
-                if (learn) serw = __builtin_fmaf(e, raw, serw);
-                rawy = cls == lab ? raw : rawy;
+                sec[ct] += e;
+                if (learn) serwc[ct] = __builtin_fmaf(e, raw, serwc[ct]);
+                rawyc[ct] = cls == lab ? raw : rawyc[ct];
                 acc[ct][st][i] = e;
             }
         }
+        float se = 0.f, serw = 0.f, rawy = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) { se += sec[ct]; serw += serwc[ct]; rawy += rawyc[ct]; }
         se += __shfl_xor(se, 32);
         serw += __shfl_xor(serw, 32);
         rawy += __shfl_xor(rawy, 32);
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         }
         const float zy = rawy * scale;
         // ---- pass 3: dZ^T (bf16, two columns per dword) ----
-        if (a.dzt != nullptr) {
+        if (a.dzt != nullptr && a.dbg != 3 && a.dbg != 4) {
             // Lanes l, l^1 hold neighbouring columns of the same class rows: each lane keeps one
             // register of a pair, receives the neighbour's copy of it by a DPP quad swap and stores
             // ONE packed dword (even lane: class row c0, odd lane: class row c0+1).
@@ -409,102 +423,108 @@ constexpr int RSF = 160;    // shorts per LDS row of the F tile: 256 B data + 64
 
 constexpr int DNS = 4;      // register stages: 3 chunks (96 KiB per CU) in flight while one is consumed
 constexpr int DIDS = 4096;  // max reduction rows per workgroup (row ids staged in LDS)
+constexpr int DMASK = (int)0x80000000;
 
-__global__ __launch_bounds__(256) void dw_bf16(DwArgsB g) {
+// 512 threads = 8 waves (2 along M x 4 along N, 64x32 outputs each): two waves per SIMD, so one
+// wave's address arithmetic / LDS traffic overlaps the other's MFMAs (with 4 waves per CU every
+// phase of a chunk was serialised: 2.9k VALU instructions per wave and 22 us measured).
+__global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     __shared__ __attribute__((aligned(16))) u16 At[DBM * RSA];
     __shared__ __attribute__((aligned(16))) u16 Ft[DKT * RSF];
     __shared__ int ids[DIDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;
     const int h = lane >> 5, l31 = lane & 31;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     // XCD-aware decode of the 1-D grid: workgroups b and b+8 share an XCD (round-robin dispatch),
-    // so split z = b % nsplit_pad keeps every tile of one K-split -- which all re-read the same
-    // dZ^T columns and feature rows -- on ONE XCD's L2 (speed only; any placement is correct).
-    const int nx = (g.N + DBN - 1) / DBN, ny = (g.M + DBM - 1) / DBM;
+    // so split z = b % nsplit keeps every tile of one K-split -- which all re-read the same dZ^T
+    // columns and feature rows -- on ONE XCD's L2 (speed only; any placement is correct).
+    const int nx = (g.N + DBN - 1) / DBN;
     const int bid = blockIdx.x;
     const int z = bid % g.nsplit, t = bid / g.nsplit;
     const int m0 = (t / nx) * DBM, n0 = (t % nx) * DBN;
-    (void)ny;
-    const int kb = z * g.k_chunk;                       // multiples of DKT
+    const int kb = z * g.k_chunk;                       // multiple of DKT
     const int ke = min(g.K, kb + g.k_chunk);
     const int nchunks = g.k_chunk / DKT;                // multiple of DNS
 
-    // row ids of this split -> LDS once (no dependent global loads inside the pipeline)
-    for (int i = tid; i < g.k_chunk; i += 256) {
+    // row ids of this split -> LDS once (no dependent global loads inside the pipeline);
+    // DMASK marks a masked (padding / out-of-range) row
+    for (int i = tid; i < g.k_chunk; i += 512) {
         int k = kb + i;
         bool seg2 = k >= g.k_switch;
         int kl = seg2 ? k - g.k_switch : k;
         int lim = seg2 ? g.k_valid2 : g.k_valid1;
         const int64_t* ip = seg2 ? g.k_rows2 : g.k_rows;
         bool valid = k < ke && kl < lim;
-        ids[i] = valid ? (int)ip[kl] : -1;              // -1: masked row
+        ids[i] = valid ? (int)ip[kl] : DMASK;
     }
     __syncthreads();
 
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    struct Stage { u32x4 a[4]; u32x4 f[4]; };
+    struct Stage { u32x4 a[2]; u32x4 f[2]; };
     Stage st[DNS];
-    // Branch-free loads: addresses clamped into valid memory, masked values zeroed by selects.
-    const int mclamp = g.M - 1 - m0;
-    auto gload = [&](Stage& sg, int c) {
-        const int k0 = kb + c * DKT;
-        const u16* abase = g.A + ((size_t)(k0 >> 6) * g.lda + m0) * 64;
+    // per-thread invariants of the two A pieces and two F pieces it stages per chunk
+    //   A piece p (0..1023): tile row p>>3, 16-B column p&7;   F piece p: chunk row p>>4, 16-B column p&15
+    const int mclamp = g.M - 1 - m0;                    // rows >= M: garbage that is never stored
+    const u16* a_thr[2];
+    int a_col[2], f_row[2], f_col[2];
+    bool f_colok[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int p = tid + 256 * q;                       // A: row p>>3, piece p&7;  F: row p>>4, piece p&15
-            int arow = min(p >> 3, mclamp);              // rows >= M: garbage that is never stored
-            // masked pieces are READ FROM A ZERO PAGE (no select on the loaded value: a select
-            // would make the compiler wait for the load right here and serialise the pipeline)
-            const u16* ap = (k0 + 8 * (p & 7) < ke) ? abase + (size_t)arow * 64 + 8 * (p & 7) : g.zeros;
+    for (int q = 0; q < 2; ++q) {
+        int p = tid + 512 * q;
+        a_col[q] = 8 * (p & 7);
+        a_thr[q] = g.A + ((size_t)m0 + min(p >> 3, mclamp)) * 64 + a_col[q];
+        f_row[q] = p >> 4;
+        f_col[q] = min(n0 + 8 * (p & 15), g.N - 8);
+        f_colok[q] = n0 + 8 * (p & 15) < g.N;
+    }
+    // Branch-free loads: masked pieces read a zero page (a select on the loaded value would make the
+    // compiler wait for the load right here and serialise the pipeline).
+    auto gload = [&](Stage& sg, int c) {
+        const int k0 = kb + c * DKT;                    // whole chunk lies in one modality (k_switch % 64 == 0)
+        const bool seg2 = k0 >= g.k_switch;
+        const u16* fb = seg2 ? g.B2 : g.B;
+        const int ld = seg2 ? g.ldb2 : g.ldb;
+        const size_t achunk = (size_t)(k0 >> 6) * g.lda * 64;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u16* ap = (k0 + a_col[q] < ke) ? a_thr[q] + achunk : g.zeros;
             sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
-            int kk = c * DKT + (p >> 4);
-            int rid = ids[kk];
-            bool seg2 = kb + kk >= g.k_switch;
-            const u16* fb = seg2 ? g.B2 : g.B;
-            int ld = seg2 ? g.ldb2 : g.ldb;
-            int ncol = n0 + 8 * (p & 15);
-            const u16* fp = (rid >= 0 && ncol < g.N) ? fb + (size_t)rid * ld + ncol : g.zeros;
+            const int rid = ids[c * DKT + f_row[q]];
+            const u16* fp = (rid != DMASK && f_colok[q]) ? fb + (size_t)rid * ld + f_col[q] : g.zeros;
             sg.f[q] = *reinterpret_cast<const u32x4*>(fp);
         }
     };
     auto lstore = [&](const Stage& sg) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int p = tid + 256 * q;
+        for (int q = 0; q < 2; ++q) {
+            int p = tid + 512 * q;
             *reinterpret_cast<u32x4*>(At + (p >> 3) * RSA + 8 * (p & 7)) = sg.a[q];
             *reinterpret_cast<u32x4*>(Ft + (p >> 4) * RSF + 8 * (p & 15)) = sg.f[q];
         }
     };
+    const u16* a_frag = At + (wm * 64 + l31) * RSA + h * 8;
+    const u16* f_frag = Ft + (8 * h + q4) * RSF + wn * 32 + (g16 & 1) * 16 + 4 * p4;
     auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < DKT / 16; ++s) {
-            bf16x8 av[2], bv[2];
+            bf16x8 av[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                av[i] = *reinterpret_cast<const bf16x8*>(At + (wm * 64 + i * 32 + l31) * RSA + s * 16 + h * 8);
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(a_frag + i * 32 * RSA + s * 16);
+            // 16-lane group g16: column block (g16&1) of the 32-wide tile, k half h = g16>>1;
+            // lane 4q+p addresses row q, columns 4p..4p+3; it receives column (lane&15), rows 0..3.
+            const u16* base = f_frag + s * 16 * RSF;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * RSF));
+            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // 16-lane group g16: column block (g16&1) of the 32-wide tile, k half h = g16>>1;
-                // lane 4q+p addresses row q, columns 4p..4p+3; it receives column (lane&15), rows 0..3.
-                const u16* base = Ft + (s * 16 + 8 * h + q4) * RSF + wn * 64 + j * 32 + (g16 & 1) * 16 + 4 * p4;
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * RSF));
-                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bv[j] = __builtin_bit_cast(bf16x8, v);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i], 0, 0, 0);
         }
     };
 
@@ -523,18 +543,16 @@ __global__ __launch_bounds__(256) void dw_bf16(DwArgsB g) {
     }
 
     float* out = g.out + (size_t)z * g.slab_stride;
+    const int n = n0 + wn * 32 + l31;
+    if (n < g.N) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int n = n0 + wn * 64 + j * 32 + l31;
-            if (n >= g.N) continue;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 int m = m0 + wm * 64 + i * 32 + acc_row(e, h);
-                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][j][e];
+                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][e];
             }
-        }
+    }
 }
 
 // --------------------------------------------------------------------------- //
@@ -595,7 +613,8 @@ int umlh_bf16_launch_dw(const DwArgsB* g, int splits, hipStream_t stream) {
     if (g->M <= 0 || g->N <= 0) return 0;
     if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
     dim3 grid(((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits);
-    hipLaunchKernelGGL(dw_bf16, grid, dim3(256), 0, stream, *g);
+    if (g->k_switch % DKT != 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dw_bf16, grid, dim3(512), 0, stream, *g);
     return (int)hipGetLastError();
 }
 
