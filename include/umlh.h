@@ -205,6 +205,11 @@ int  umlh_seq_mse_forward(const float* z, const float* w, const float* bias, con
 int  umlh_seq_mse_backward(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out,
                            int32_t B, int32_t T, int32_t Z, int32_t D, float* dz, float* dw, float* db, void* stream);
 
+/* A pseudo-random permutation of 0..n-1 written as int64 (device), keyed by seed: 4-round Feistel
+ * network + cycle walking, no sort.  Epoch shuffles for throughput runs; NOT the reference's
+ * sampler order (that is reproduced host-side by the loader, finetune.py:370-371). */
+int  umlh_random_permutation(int64_t n, uint64_t seed, int64_t* out, void* stream);
+
 /* Standalone optimizer.step() for one parameter tensor from a caller-computed
  * gradient (engine/optimizer/optim.py:34-71; torch.optim single-tensor recurrences):
  * the same update kernel the fused step applies.  v may be NULL for SGD. */

@@ -255,3 +255,19 @@ def test_argument_errors_are_loud():
         e.train_step(_rb(x, y), None, lr=1e-3, step=1)          # rows > capacity
     with pytest.raises(umlh.UmlhError):
         e.train_step(None, None, lr=1e-3, step=1)               # finetune.py:123
+
+
+def test_device_permutation_is_a_bijection_and_seed_dependent():
+    import umlh
+    for n in (1, 2, 7, 4096, 29940, 1281167):
+        p = umlh.random_permutation(n, 12345, DEV)
+        assert torch.equal(torch.sort(p).values, torch.arange(n, device=DEV))
+    a, b = umlh.random_permutation(29940, 1, DEV), umlh.random_permutation(29940, 2, DEV)
+    assert not torch.equal(a, b)
+    assert (a == torch.arange(29940, device=DEV)).float().mean() < 0.01       # not the identity
+    # epoch coverage through the loader: every row exactly once per epoch
+    from engine.datasets.utils import FeatureLoader, FeatureTable
+    ld = FeatureLoader(FeatureTable(torch.zeros(1000, 4), torch.zeros(1000, dtype=torch.long), DEV), 96, shuffle=True,
+                       order_rng="device")
+    seen = torch.cat(list(ld.iter_index()))
+    assert seen.numel() == 1000 and torch.equal(torch.sort(seen).values, torch.arange(1000, device=DEV))

@@ -371,6 +371,14 @@ int umlh_seq_mse_backward(const float* z, const float* w, const float* dres, con
     return UMLH_OK;
 }
 
+extern "C" int umlh_launch_feistel_perm(long long n, unsigned long long seed, long long* out, hipStream_t stream);
+
+int umlh_random_permutation(int64_t n, uint64_t seed, int64_t* out, void* stream) {
+    if (n < 0 || (n > 0 && !out)) return fail(UMLH_E_INVALID, "umlh_random_permutation: bad arguments");
+    HIPCHK(umlh_launch_feistel_perm(n, seed, reinterpret_cast<long long*>(out), (hipStream_t)stream), "feistel perm");
+    return UMLH_OK;
+}
+
 int umlh_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
     if (!src || !dst || n < 0) return fail(UMLH_E_INVALID, "umlh_to_bf16: bad arguments");
     HIPCHK(umlh_launch_to_bf16(src, dst, n, (hipStream_t)stream), "to_bf16");

@@ -594,6 +594,39 @@ __global__ __launch_bounds__(256) void zero_shot_kernel(const float* __restrict_
 }
 
 // --------------------------------------------------------------------------- //
+// epoch shuffles without a sort: out[i] = pi(i), pi = 4-round Feistel network over 2*half bits
+// keyed by `seed`, restricted to [0, n) by cycle walking (a bijection; O(1) per element).
+// Used for throughput-mode loaders (order_rng="device"); reference-identical orders come from
+// the CPU sampler restatement instead.
+// --------------------------------------------------------------------------- //
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void feistel_perm_kernel(long long n, unsigned long long seed, int half,
+                                                           long long* __restrict__ out) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long mask = (1ULL << half) - 1ULL;
+    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    unsigned long long x = (unsigned long long)i;
+    do {
+        unsigned long long L = x >> half, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            unsigned long long F = (unsigned long long)mix32((unsigned)R * 0x9e3779b1U + (r & 1 ? k1 : k0) + 0x85ebca6bU * (unsigned)r +
+                                                               (unsigned)(R >> 32)) & mask;
+            unsigned long long nl = R;
+            R = L ^ F;
+            L = nl;
+        }
+        x = (L << half) | R;
+    } while (x >= (unsigned long long)n);
+    out[i] = (long long)x;
+}
+
+// --------------------------------------------------------------------------- //
 // launchers (called from umlh_api.cpp)
 // --------------------------------------------------------------------------- //
 extern "C" {
@@ -667,6 +700,15 @@ int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride
     int blocks = (int)((n8 + 255) / 256) + 1;                 // + the finalize block
     hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, *o,
                        (unsigned short*)shadow, cpad, *f, grad_out);
+    return (int)hipGetLastError();
+}
+
+int umlh_launch_feistel_perm(long long n, unsigned long long seed, long long* out, hipStream_t stream) {
+    if (n <= 0) return 0;
+    int bits = 1;
+    while ((1LL << bits) < n) ++bits;
+    int half = (bits + 1) / 2;
+    hipLaunchKernelGGL(feistel_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, seed, half, out);
     return (int)hipGetLastError();
 }
 

@@ -154,10 +154,8 @@ class _IndexIter:
             if ld.shuffle:
                 seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler seed
                 if ld.order_rng == "device":
-                    if ld._dev_gen is None:
-                        ld._dev_gen = torch.Generator(device=ld.table.device)
-                    ld._dev_gen.manual_seed(seed)
-                    self.order = torch.randperm(n, generator=ld._dev_gen, device=ld.table.device)
+                    import umlh
+                    self.order = umlh.random_permutation(n, seed, ld.table.device)   # one tiny kernel, no sort
                 else:
                     g = torch.Generator()
                     g.manual_seed(seed)

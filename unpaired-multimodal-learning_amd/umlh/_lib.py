@@ -23,7 +23,8 @@ EXPORTS = ["umlh_last_error", "umlh_version", "umlh_workspace_bytes", "umlh_crea
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
-           "umlh_train_steps", "umlh_seq_mse_forward", "umlh_seq_mse_backward"]
+           "umlh_train_steps", "umlh_seq_mse_forward", "umlh_seq_mse_backward",
+           "umlh_random_permutation"]
 
 
 class UmlhError(RuntimeError):
@@ -119,6 +120,7 @@ def load_library():
                                      C.c_float, C.c_float, vp, vp]
     lib.umlh_seq_mse_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.umlh_seq_mse_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.umlh_random_permutation.argtypes = [i64, u64, vp, vp]
     lib.umlh_profile_enable.argtypes = [vp, C.c_int]
     lib.umlh_profile_read.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:

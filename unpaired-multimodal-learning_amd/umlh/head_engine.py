@@ -307,3 +307,12 @@ def to_bf16(t: torch.Tensor) -> torch.Tensor:
     st = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     check(lib.umlh_to_bf16(_ptr(t), _ptr(out), t.numel(), st), "umlh_to_bf16")
     return out
+
+
+def random_permutation(n: int, seed: int, device) -> torch.Tensor:
+    """int64 permutation of 0..n-1 drawn on the device by ``umlh_random_permutation`` (sort-free)."""
+    lib = _lib.load_library()
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    st = C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
+    check(lib.umlh_random_permutation(int(n), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(out), st), "umlh_random_permutation")
+    return out
