@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default=os.environ.get("UMLH_PRECISION", "bf16"), choices=["fp32", "bf16"],
                     help="bf16 = BASELINE config 2 (headline); fp32 = exact-parity mode")
+    ap.add_argument("--force-dp-path", action="store_true", help="N=1 only: run the data-parallel split path (grad_step -> [all_reduce] -> apply_update, per-step host loop) to price it")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the additional fp32 parity-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--order-rng", default="device", choices=["device", "torch-cpu"],
@@ -104,7 +105,7 @@ def main():
 
         def one_step():
             ii, ti = img_src.next_index(), txt_src.next_index()
-            if world > 1:       # grad -> all-reduce -> update, lean host path
+            if world > 1 or args.force_dp_path:       # grad -> all-reduce -> update, lean host path
                 stepper.step_indexed(ii, ti, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1,
                                      alpha=1.0, scalars_out=scal[cursor["k"]])
             else:
@@ -121,7 +122,7 @@ def main():
             """N=1: blocks of `--block` steps through ONE umlh_train_steps call each (the host prepares
             the next block's index vectors while the GPU runs); N>1: per-step DP stepping."""
             rows = 0
-            if world > 1:
+            if world > 1 or args.force_dp_path:
                 for _ in range(n):
                     rows += one_step()
                 return rows

@@ -251,3 +251,103 @@ def setup_feature_run(img_train, img_val, img_test, text_ds, hparams, *, num_cla
     test_loss, test_acc = validate(model, test_loader, device=device)
     return {"test_acc": test_acc, "test_loss": test_loss, "val_acc": result["val_acc"], "model": result["model"],
             "iter": result["iter"], "train_scalars": result["train_scalars"]}
+
+
+# --------------------------------------------------------------------------------------------- #
+# sweep / main over feature files  (reference: finetune.py:58-77 naming, :323-448 setup/sweep,
+# :451-510 main).  Same flag names on `args`; wandb / Tee logging and raw-image loading are out
+# of scope -- images come from the feature files features.py wrote.
+# --------------------------------------------------------------------------------------------- #
+FLAG = 0   # run despite an existing result file when set to 1 (reference finetune.py:31)
+
+
+def savedir(outdir, dataset, encoder, train_shot, seed, text_type, text_shots, image_augmentation, mode,
+            init_mode="zeroshot", alpha=0.0, text_bs=0, custom_name="", args=None):
+    from features import get_few_shot_setup_name
+    benchname = "-".join([dataset, get_few_shot_setup_name(train_shot, seed)])
+    text_name = f"text_{text_type}" + (f"_n_{text_shots}" if text_shots is not None else "")
+    image_name = f"image_{image_augmentation}_{custom_name}"
+    mod_name = (f"finetune-{text_name}-{image_name}" if mode == "crossmodal"
+                else f"finetune-{image_name}" if mode == "image" else text_name)
+    if mode == "crossmodal":
+        mod_name = f"{mod_name}-alpha_{alpha}"
+    if text_bs > 0:
+        mod_name = f"{mod_name}-text_bs_{text_bs}"
+    if args is not None and mode != "crossmodal":
+        mod_name = f"{mod_name}-common_dim_{getattr(args, 'common_dim', 0)}"
+    return os.path.join(outdir, benchname, encoder.replace("/", "-"), mod_name, init_mode)
+
+
+def setup(datasets, hparams, args):
+    """One hyper-parameter point: build model / optimizer / scheduler / loaders, train, test, save
+    ``test_result.pth`` (skipped when it exists and FLAG is 0, reference :330-333)."""
+    ckpt_dir = os.path.join(args.savepath, hparam_str(hparams["optim"], hparams["lr"], hparams["weight_decay"],
+                                                      hparams["batch_size"], hparams["max_iter"], hparams["dropout"],
+                                                      hparams["learnable_temp"]))
+    os.makedirs(ckpt_dir, exist_ok=True)
+    test_path = os.path.join(ckpt_dir, "test_result.pth")
+    if os.path.exists(test_path) and not FLAG:
+        print(f"=> Skipping {ckpt_dir} as it already exists!")
+        return torch.load(test_path, map_location="cpu", weights_only=True)
+    res = setup_feature_run(datasets["img_tr"], datasets["img_val"], datasets["img_te"], datasets["text_ds"], hparams,
+                            num_classes=args.nclasses, modality=args.modality, alpha=args.alpha,
+                            classifier_init=args.classifier_init, use_clip=args.use_clip, clip_logit=args.logit,
+                            text_indim=getattr(args, "text_indim", None) if args.modality == "crossmodal"
+                            else getattr(args, "common_dim", 0), device=args.device,
+                            eval_test=getattr(args, "eval_test", True), precision=getattr(args, "precision", "fp32"))
+    test_dict = {"test_acc": res["test_acc"], "val_acc": res["val_acc"], "model": res["model"], "iter": res["iter"]}
+    print(f"=> Test Acc: {res['test_acc']:.4f}")
+    torch.save(test_dict, test_path)
+    return test_dict
+
+
+def sweep(datasets, hyperparams, args):
+    """Cartesian product over the list-valued entries of a HYPER_DICT grid, in key order
+    (reference :406-448); returns (results, best_val_acc, best_test_acc)."""
+    from itertools import product
+    grid = {k: (v if isinstance(v, list) else [v]) for k, v in hyperparams.items()}
+    keys = list(grid)
+    results = {"test_acc": [], "val_acc": [], "hparams": [], "model_records": []}
+    for idx, combo in enumerate(product(*[grid[k] for k in keys])):
+        hp = dict(zip(keys, combo))
+        print(f"=> Running {idx + 1}: {hp}")
+        out = setup(datasets, hp, args)
+        results["test_acc"].append(out["test_acc"])
+        results["val_acc"].append(out["val_acc"])
+        results["hparams"].append(hp)
+    torch.save(results, os.path.join(args.savepath, "results.pth"))
+    best = int(torch.argmax(torch.tensor(results["val_acc"])))
+    print(f"=> [FINAL] Best Val Acc: {results['val_acc'][best]:.4f} | Best Test Acc: {results['test_acc'][best]:.4f}")
+    print(f"=> [FINAL] Best Hyperparameters: {results['hparams'][best]}")
+    return results, results["val_acc"][best], results["test_acc"][best]
+
+
+def main(args):
+    """``finetune.main`` (reference :451-510) over pre-extracted feature files: seeds, resolves the
+    feature paths with the reference's scheme, builds the text dataset, sweeps HYPER_DICT[args.hyperparams]."""
+    import features as F_
+    from engine.tools.utils import set_random_seed
+    if args.seed >= 0:
+        set_random_seed(args.seed)
+    args.device = getattr(args, "device", None) or "cuda:0"
+    args.use_clip = getattr(args, "vision_model", "") == "" and getattr(args, "language_model", "") == ""
+    enc_img = args.clip_encoder if args.use_clip else args.vision_model
+    enc_txt = args.clip_encoder if args.use_clip else args.language_model
+    encoder_name = enc_img if args.use_clip else f"{args.vision_model}-{args.language_model}"
+    args.savepath = savedir(args.result_dir, args.dataset, encoder_name, args.train_shot, args.seed, args.text_type,
+                            args.text_shot, args.image_augmentation, args.modality, args.classifier_init, args.alpha,
+                            getattr(args, "text_batch_size", 0), getattr(args, "custom_name", ""), args)
+    os.makedirs(args.savepath, exist_ok=True)
+    text = F_.load_text_features(F_.text_outdir(args.feature_dir, enc_txt, args.dataset, args.text_type))
+    shots = args.text_shot
+    text_ds = TextTensorDataset(text["features"], text["labels"], text["eot_indices"],
+                                n_shots=int(shots) if (shots != "average" and shots is not None) else shots)
+    tr = F_.load_image_train_features(F_.img_outdir(args.feature_dir, enc_img, args.dataset, args.image_augmentation,
+                                                    args.train_shot, args.seed, "train"))
+    te = F_.load_image_test_features(F_.img_outdir(args.feature_dir, enc_img, args.dataset, args.image_augmentation,
+                                                   args.train_shot, args.seed, "test"))
+    args.img_indim, args.text_indim = tr["train"][0].shape[1], text["features"].shape[1]
+    lab2cname = tr.get("lab2cname") or text.get("lab2cname")
+    args.nclasses = len(lab2cname) if lab2cname else int(max(tr["train"][1].max(), te["test"][1].max())) + 1
+    datasets = {"img_tr": tr["train"], "img_val": tr["val"], "img_te": te["test"], "text_ds": text_ds}
+    return sweep(datasets, HYPER_DICT[args.hyperparams] if isinstance(args.hyperparams, str) else args.hyperparams, args)
