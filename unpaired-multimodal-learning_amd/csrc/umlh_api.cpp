@@ -37,7 +37,7 @@ struct SegDescB {
 struct FwdArgsB { SegDescB seg[2]; const u16* W; int C, K; u16* dzt; int crows; float* partials; int dbg; int learn; };
 struct DwArgsB {
     const u16* A; const u16* B; const int64_t* k_rows; int ldb; const u16* B2; const int64_t* k_rows2; int ldb2;
-    float* out; const u16* zeros; int M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit; long long slab_stride;
+    float* out; const u16* zeros; int dbg; int M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit; long long slab_stride;
 };
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
@@ -467,6 +467,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         g.M = c.num_classes; g.N = c.d_shared; g.K = rcols_b;
         g.k_chunk = chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
         g.nsplit = splits;
+        { const char* e = getenv("UMLH_DBG_DW"); g.dbg = e ? atoi(e) : 0; }
         HIPCHK(umlh_bf16_launch_dw(&g, splits, st), "dw_bf16");
         *n_slabs_head = splits;
         mark(h, 3, st);

@@ -104,6 +104,7 @@ struct DwArgsB {
     const u16* B2; const int64_t* k_rows2; int ldb2;    // text-side feature rows (k >= k_switch)
     float* out;                  // fp32 slabs [splits][M][ldo]
     const u16* zeros;            // >= 16 B of zeros (source of masked loads)
+    int   dbg;                   // timing-only ablations: bit0 = no A traffic, bit1 = no F traffic
     int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit;
     long long slab_stride;
 };
@@ -429,8 +430,9 @@ constexpr int DMASK = (int)0x80000000;
 // wave's address arithmetic / LDS traffic overlaps the other's MFMAs (with 4 waves per CU every
 // phase of a chunk was serialised: 2.9k VALU instructions per wave and 22 us measured).
 __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
-    __shared__ __attribute__((aligned(16))) u16 At[DBM * RSA];
-    __shared__ __attribute__((aligned(16))) u16 Ft[DKT * RSF];
+    // two LDS buffers: chunk c+1 is written while chunk c is consumed -> ONE barrier per chunk
+    __shared__ __attribute__((aligned(16))) u16 At[2][DBM * RSA];
+    __shared__ __attribute__((aligned(16))) u16 Ft[2][DKT * RSF];
     __shared__ int ids[DIDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -446,19 +448,6 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     const int kb = z * g.k_chunk;                       // multiple of DKT
     const int ke = min(g.K, kb + g.k_chunk);
     const int nchunks = g.k_chunk / DKT;                // multiple of DNS
-
-    // row ids of this split -> LDS once (no dependent global loads inside the pipeline);
-    // DMASK marks a masked (padding / out-of-range) row
-    for (int i = tid; i < g.k_chunk; i += 512) {
-        int k = kb + i;
-        bool seg2 = k >= g.k_switch;
-        int kl = seg2 ? k - g.k_switch : k;
-        int lim = seg2 ? g.k_valid2 : g.k_valid1;
-        const int64_t* ip = seg2 ? g.k_rows2 : g.k_rows;
-        bool valid = k < ke && kl < lim;
-        ids[i] = valid ? (int)ip[kl] : DMASK;
-    }
-    __syncthreads();
 
     f32x16 acc[2];
 #pragma unroll
@@ -485,32 +474,41 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     }
     // Branch-free loads: masked pieces read a zero page (a select on the loaded value would make the
     // compiler wait for the load right here and serialise the pipeline).
-    auto gload = [&](Stage& sg, int c) {
+    auto gloadA = [&](Stage& sg, int c) {
+        const int k0 = kb + c * DKT;
+        const size_t achunk = (size_t)(k0 >> 6) * g.lda * 64;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u16* ap = (k0 + a_col[q] < ke && !(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
+            sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
+        }
+    };
+    auto gloadF = [&](Stage& sg, int c) {
         const int k0 = kb + c * DKT;                    // whole chunk lies in one modality (k_switch % 64 == 0)
         const bool seg2 = k0 >= g.k_switch;
         const u16* fb = seg2 ? g.B2 : g.B;
         const int ld = seg2 ? g.ldb2 : g.ldb;
-        const size_t achunk = (size_t)(k0 >> 6) * g.lda * 64;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const u16* ap = (k0 + a_col[q] < ke) ? a_thr[q] + achunk : g.zeros;
-            sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
             const int rid = ids[c * DKT + f_row[q]];
-            const u16* fp = (rid != DMASK && f_colok[q]) ? fb + (size_t)rid * ld + f_col[q] : g.zeros;
+            const u16* fp = (rid != DMASK && f_colok[q] && !(g.dbg & 2)) ? fb + (size_t)rid * ld + f_col[q] : g.zeros;
             sg.f[q] = *reinterpret_cast<const u32x4*>(fp);
         }
     };
-    auto lstore = [&](const Stage& sg) {
+    auto gload = [&](Stage& sg, int c) { gloadA(sg, c); gloadF(sg, c); };
+    auto lstore = [&](const Stage& sg, int buf) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             int p = tid + 512 * q;
-            *reinterpret_cast<u32x4*>(At + (p >> 3) * RSA + 8 * (p & 7)) = sg.a[q];
-            *reinterpret_cast<u32x4*>(Ft + (p >> 4) * RSF + 8 * (p & 15)) = sg.f[q];
+            *reinterpret_cast<u32x4*>(At[buf] + (p >> 3) * RSA + 8 * (p & 7)) = sg.a[q];
+            *reinterpret_cast<u32x4*>(Ft[buf] + (p >> 4) * RSF + 8 * (p & 15)) = sg.f[q];
         }
     };
-    const u16* a_frag = At + (wm * 64 + l31) * RSA + h * 8;
-    const u16* f_frag = Ft + (8 * h + q4) * RSF + wn * 32 + (g16 & 1) * 16 + 4 * p4;
-    auto compute = [&]() {
+    const int a_off = (wm * 64 + l31) * RSA + h * 8;
+    const int f_off = (8 * h + q4) * RSF + wn * 32 + (g16 & 1) * 16 + 4 * p4;
+    auto compute = [&](int buf) {
+        const u16* a_frag = At[buf] + a_off;
+        const u16* f_frag = Ft[buf] + f_off;
 #pragma unroll
         for (int s = 0; s < DKT / 16; ++s) {
             bf16x8 av[2];
@@ -528,17 +526,38 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
         }
     };
 
+    // row ids of this split -> LDS once (no dependent global loads inside the pipeline); DMASK marks a
+    // masked (padding / out-of-range) row.  The id-independent dZ^T loads of the first DNS chunks are
+    // issued first so their latency overlaps this round trip.
     const int lastc = nchunks - 1;
 #pragma unroll
-    for (int d = 0; d < DNS; ++d) gload(st[d], min(d, lastc));
+    for (int d = 0; d < DNS; ++d) gloadA(st[d], min(d, lastc));
+    for (int i = tid; i < g.k_chunk; i += 512) {
+        int k = kb + i;
+        bool seg2 = k >= g.k_switch;
+        int kl = seg2 ? k - g.k_switch : k;
+        int lim = seg2 ? g.k_valid2 : g.k_valid1;
+        const int64_t* ip = seg2 ? g.k_rows2 : g.k_rows;
+        bool valid = k < ke && kl < lim;
+        ids[i] = valid ? (int)ip[kl] : DMASK;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DNS; ++d) gloadF(st[d], min(d, lastc));
+    lstore(st[0], 0);                                   // chunk 0 -> buffer 0
+    gload(st[0], min(DNS, lastc));
+    __syncthreads();
+    // iteration for chunk c (buffer c&1): stage chunk c+1 into the other buffer, refill its register
+    // stage with chunk c+1+DNS, run the MFMAs of chunk c, one barrier.  DNS is even, so (c+1)&1 and
+    // the stage index (c+1)%DNS are compile-time constants inside the unrolled body.
     for (int c = 0; c < nchunks; c += DNS) {
 #pragma unroll
         for (int d = 0; d < DNS; ++d) {
+            const int nd = (d + 1) % DNS;
+            lstore(st[nd], (d + 1) & 1);              // (past the end: a harmless re-store of the last chunk)
+            gload(st[nd], min(c + d + 1 + DNS, lastc));
+            compute(d & 1);
             __syncthreads();
-            lstore(st[d]);
-            __syncthreads();
-            gload(st[d], min(c + d + DNS, lastc));
-            compute();
         }
     }
 
