@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct) ring[d][ct] = wfrag(min(d, nks - 1), ct);
 
-    for (int kb0 = 0; kb0 < (a.dbg == 2 ? 0 : K); kb0 += XK) {
+    for (int kb0 = 0; kb0 < ((a.dbg == 2 || a.dbg == 5) ? 0 : K); kb0 += XK) {
         const int kbw = min(XK, K - kb0);                        // multiple of 128
         // ---- stage the X block: global -> registers -> LDS ----
         u32x4 xr[NPX];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         }
     }
 
-    if (a.dbg == 1) {                                  // ablation: keep the accumulators live, skip the epilogue
+    if (a.dbg == 1 || a.dbg == 5) {                    // ablation: keep the accumulators live, skip the epilogue
         float t = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct)
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     // iteration for chunk c (buffer c&1): stage chunk c+1 into the other buffer, refill its register
     // stage with chunk c+1+DNS, run the MFMAs of chunk c, one barrier.  DNS is even, so (c+1)&1 and
     // the stage index (c+1)%DNS are compile-time constants inside the unrolled body.
-    for (int c = 0; c < nchunks; c += DNS) {
+    for (int c = 0; c < ((g.dbg & 4) ? 0 : nchunks); c += DNS) {      // dbg bit2: skip the main loop (fixed-cost probe)
 #pragma unroll
         for (int d = 0; d < DNS; ++d) {
             const int nd = (d + 1) % DNS;
