@@ -13,6 +13,7 @@
 //   finalize       per-step scalars + the two learnable logit scales
 //   zero_shot      head.py:22-37
 #include "umlh_common.h"
+#include <cstdlib>
 
 // --------------------------------------------------------------------------- //
 // staging helpers: global -> registers -> LDS, k-major LDS tiles [KT][LD]
@@ -39,7 +40,10 @@ __device__ __forceinline__ f32x4v load4_guard(const float* p, int lim, bool vec_
 // issued "swapped" (A = W class tile, B = X sample tile) so that every lane owns ONE
 // sample (column) and 16*CTW of its class logits (rows) in registers: the softmax
 // reductions over classes are in-lane, then one half-swap, then WC values via LDS.
-template <int CTW, int WC>
+// FAST (host-checked: K % 16 == 0, 16-B aligned operands): every load is an unconditional 16-B
+// vector load from a clamped address, so the compiler keeps counted vmcnt waits instead of
+// branching around guarded loads (out-of-range rows load a valid row; their results are masked).
+template <int CTW, int WC, bool FAST>
 __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     constexpr int WS = 8 / WC;
     constexpr int CPAD = 32 * CTW * WC;
@@ -70,17 +74,28 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
 #pragma unroll
     for (int q = 0; q < NPW; ++q) {
         int p = tid + 512 * q, cls = p >> 2;
-        wsrc[q] = (p < CPAD * 4 && cls < C) ? a.W + (size_t)cls * K : nullptr;
+        if (FAST) wsrc[q] = a.W + (size_t)min(cls, C - 1) * K;        // rows >= C: logits masked to -inf below
+        else wsrc[q] = (p < CPAD * 4 && cls < C) ? a.W + (size_t)cls * K : nullptr;
     }
 #pragma unroll
     for (int q = 0; q < NPX; ++q) {
         int p = tid + 512 * q, smp = p >> 2, r = row0 + smp;
         const float* s = nullptr;
-        if (p < TS * 4 && r < sg.rows) {
+        if (FAST) {
+            int rc = min(r, sg.rows - 1);                              // rows past the segment: coef = 0 below
+            int64_t rid = sg.feat_index ? sg.feat_index[rc] : (int64_t)rc;
+            s = sg.feats + (size_t)rid * sg.ld;
+        } else if (p < TS * 4 && r < sg.rows) {
             int64_t rid = sg.feat_index ? sg.feat_index[r] : (int64_t)r;
             s = sg.feats + (size_t)rid * sg.ld;
         }
         xsrc[q] = s;
+    }
+    // label of this lane's sample: dependent loads issued before the main loop hides them
+    int lab_pre;
+    {
+        int rc = min(row0 + (wave / WC) * 32 + (lane & 31), sg.rows - 1);
+        lab_pre = (int)sg.labels[sg.label_index ? sg.label_index[rc] : (int64_t)rc];
     }
 
     f32x16 acc[CTW];
@@ -95,13 +110,15 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
         for (int q = 0; q < NPW; ++q) {
             int g = (tid + 512 * q) & 3;
             int k = k0 + 4 * g;
-            wreg[q] = wsrc[q] ? load4_guard(wsrc[q] + k, K - k, vecW) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (FAST) wreg[q] = *reinterpret_cast<const f32x4v*>(wsrc[q] + k);
+            else wreg[q] = wsrc[q] ? load4_guard(wsrc[q] + k, K - k, vecW) : f32x4v{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int q = 0; q < NPX; ++q) {
             int g = (tid + 512 * q) & 3;
             int k = k0 + 4 * g;
-            xreg[q] = xsrc[q] ? load4_guard(xsrc[q] + k, K - k, vecX) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (FAST) xreg[q] = *reinterpret_cast<const f32x4v*>(xsrc[q] + k);
+            else xreg[q] = xsrc[q] ? load4_guard(xsrc[q] + k, K - k, vecX) : f32x4v{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto lstore = [&]() {
@@ -130,7 +147,8 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
         __syncthreads();
         lstore();
         __syncthreads();
-        if (k0 + KT < K) gload(k0 + KT);
+        if (FAST) gload(min(k0 + KT, K - KT));          // branch-free: the last prefetch re-loads the last chunk
+        else if (k0 + KT < K) gload(k0 + KT);
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
             const int krow = 2 * kk + h;
@@ -148,8 +166,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     const int smp = ws * 32 + l31;
     const int r = row0 + smp;
     const bool valid = r < sg.rows;
-    int lab = -1;
-    if (valid) lab = (int)sg.labels[sg.label_index ? sg.label_index[r] : (int64_t)r];
+    const int lab = valid ? lab_pre : -1;
 
     const float NEG_INF = -__builtin_huge_valf();
     float mx = NEG_INF;
@@ -210,8 +227,8 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
         }
     }
 
-    if (a.dzt != nullptr && valid) {
-        const float coef = sg.w_over_rows * scale;
+    if (a.dzt != nullptr) {       // rows past the segment write zeros: the dW GEMM needs no masking of dZ^T
+        const float coef = valid ? sg.w_over_rows * scale : 0.f;
         const float inv = 1.f / se;
         float* dst = a.dzt + sg.col0 + r;
 #pragma unroll
@@ -255,10 +272,13 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
 // each wave 64x64 = 2x2 MFMA tiles.  TA/TB = 0: operand stored with k contiguous
 // (A[m*lda+k]);  = 1: stored k-major (A[k*lda+m]).  blockIdx.z = split-K slab.
 // --------------------------------------------------------------------------- //
-constexpr int GBM = 128, GBN = 128, GLD = 132;
+// tile = 64*TM x 64*TM, 4 waves (2x2) of TM x TM MFMA tiles each.  TM = 2 (128x128) maximises reuse; TM = 1
+// (64x64) quadruples the workgroup count for GEMMs whose 128x128 grid cannot fill the chip.
+constexpr int GKIDS = 4096;   // reduction rows per split whose row ids fit the LDS table
 
-template <int TA, int TB>
+template <int TA, int TB, int TM>
 __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
+    constexpr int GBM = 64 * TM, GBN = 64 * TM, GLD = GBM + 4;
     __shared__ __attribute__((aligned(16))) float As[KT * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[KT * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -272,21 +292,21 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
         return k < g.k_switch ? (k < g.k_valid1) : (k - g.k_switch < g.k_valid2);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    f32x4v areg[2], breg[2];
-    // ---- A ----
-    const float* a_src[2];
+    f32x4v areg[TM], breg[TM];
+    // ---- A ----  (GBM*4 16-B pieces per chunk = TM per thread)
+    const float* a_src[TM];
     const bool vecA = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
     if (TA == 0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < TM; ++q) {
             int p = tid + 256 * q, row = p >> 2, m = m0 + row;
             const float* s = nullptr;
             if (m < g.M) {
@@ -298,18 +318,34 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
     }
     const bool vecB = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
     const bool vecB2 = TB == 1 && g.B2 && (g.ldb2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B2) & 15) == 0);
-    const float* b_src[2];
+    const float* b_src[TM];
     if (TB == 0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < TM; ++q) {
             int p = tid + 256 * q, row = p >> 2, n = n0 + row;
             b_src[q] = n < g.N ? g.B + (size_t)n * g.ldb : nullptr;
         }
     }
+    // TB == 1: the gathered row id of every reduction row of this split is staged in LDS once.
+    // Loading it per chunk made each chunk pay a dependent index->row round trip (~2 us x 64 chunks
+    // on the cfg2 dW GEMM).  -1 = masked row.
+    __shared__ int kid[GKIDS];
+    const bool use_kid = TB == 1 && (ke - kb) <= GKIDS;
+    if (use_kid) {
+        for (int i = tid; i < ke - kb; i += 256) {
+            int k = kb + i, rid = -1;
+            if (kvalid(k)) {
+                if (k < g.k_switch) rid = g.k_rows ? (int)g.k_rows[k] : k;
+                else { int kl = k - g.k_switch; rid = g.k_rows2 ? (int)g.k_rows2[kl] : kl; }
+            }
+            kid[i] = rid;
+        }
+        __syncthreads();
+    }
 
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < TM; ++q) {
             int p = tid + 256 * q;
             if (TA == 0) {                       // piece = (row m, 4 consecutive k)
                 int k = k0 + 4 * (p & 3);
@@ -320,7 +356,7 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
                 }
                 areg[q] = v;
             } else {                             // piece = (k row, 4 consecutive m)
-                int kk = p >> 5, mm = m0 + 4 * (p & 31), k = k0 + kk;
+                int kk = p / (GBM / 4), mm = m0 + 4 * (p % (GBM / 4)), k = k0 + kk;
                 areg[q] = (k < ke) ? load4_guard(g.A + (size_t)k * g.lda + mm, g.M - mm, vecA)
                                    : f32x4v{0.f, 0.f, 0.f, 0.f};
             }
@@ -328,9 +364,15 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
                 int k = k0 + 4 * (p & 3);
                 breg[q] = b_src[q] ? load4_guard(b_src[q] + k, ke - k, vecB) : f32x4v{0.f, 0.f, 0.f, 0.f};
             } else {
-                int kk = p >> 5, nn = n0 + 4 * (p & 31), k = k0 + kk;
+                int kk = p / (GBN / 4), nn = n0 + 4 * (p % (GBN / 4)), k = k0 + kk;
                 f32x4v v = {0.f, 0.f, 0.f, 0.f};
-                if (k < ke && kvalid(k)) {
+                if (use_kid) {
+                    int rid = k < ke ? kid[k - kb] : -1;
+                    if (rid >= 0) {
+                        const bool s2 = k >= g.k_switch;
+                        v = load4_guard((s2 ? g.B2 : g.B) + (size_t)rid * (s2 ? g.ldb2 : g.ldb) + nn, g.N - nn, s2 ? vecB2 : vecB);
+                    }
+                } else if (k < ke && kvalid(k)) {
                     if (k < g.k_switch) {
                         int64_t rid = g.k_rows ? g.k_rows[k] : (int64_t)k;
                         v = load4_guard(g.B + (size_t)rid * g.ldb + nn, g.N - nn, vecB);
@@ -346,14 +388,14 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < TM; ++q) {
             int p = tid + 256 * q;
             if (TA == 0) {
                 int row = p >> 2, gq = p & 3;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) As[(4 * gq + j) * GLD + row] = areg[q][j];
             } else {
-                int kk = p >> 5, mm = 4 * (p & 31);
+                int kk = p / (GBM / 4), mm = 4 * (p % (GBM / 4));
                 *reinterpret_cast<f32x4v*>(&As[kk * GLD + mm]) = areg[q];
             }
             if (TB == 0) {
@@ -361,7 +403,7 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Bs[(4 * gq + j) * GLD + row] = breg[q][j];
             } else {
-                int kk = p >> 5, nn = 4 * (p & 31);
+                int kk = p / (GBN / 4), nn = 4 * (p % (GBN / 4));
                 *reinterpret_cast<f32x4v*>(&Bs[kk * GLD + nn]) = breg[q];
             }
         }
@@ -376,15 +418,15 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
             const int krow = 2 * kk + h;
-            float av[2], bv[2];
+            float av[TM], bv[TM];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = As[krow * GLD + wm * 64 + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) av[i] = As[krow * GLD + wm * 32 * TM + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = Bs[krow * GLD + wn * 64 + j * 32 + l31];
+            for (int j = 0; j < TM; ++j) bv[j] = Bs[krow * GLD + wn * 32 * TM + j * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -392,14 +434,14 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
     float* out = g.out + (size_t)blockIdx.z * g.slab_stride;
     const float alpha = g.alpha * (g.alpha_ptr ? *g.alpha_ptr : 1.f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int n = n0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < TM; ++j) {
+            int n = n0 + wn * 32 * TM + j * 32 + l31;
             if (n >= g.N) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                int m = m0 + wm * 64 + i * 32 + acc_row(e, h);
+                int m = m0 + wm * 32 * TM + i * 32 + acc_row(e, h);
                 if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][j][e] * alpha;
             }
         }
@@ -649,34 +691,43 @@ static size_t fwd_smem_bytes(int ctw, int wc) {
     return sizeof(float) * (size_t)(KT * (cpad + 4) + KT * (ts + 4) + wc * ts * 4 + ws * 4 + 16);
 }
 
-#define FWD_CASE(CT, W)                                                                             \
-    if (ctw == CT && wc == W) {                                                                     \
+#define FWD_CASE_F(CT, W, F)                                                                        \
+    if (ctw == CT && wc == W && fast == F) {                                                        \
         size_t sm = fwd_smem_bytes(CT, W);                                                          \
         static bool attr_done = false;                     /* once per instantiation, not per launch */ \
         if (!attr_done) {                                                                           \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_f32<CT, W>),   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_f32<CT, W, F>),\
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);\
             if (e != hipSuccess) return (int)e;                                                     \
             attr_done = true;                                                                       \
         }                                                                                           \
-        hipLaunchKernelGGL((fwd_ce_f32<CT, W>), dim3(grid), dim3(512), sm, stream, *a);             \
+        hipLaunchKernelGGL((fwd_ce_f32<CT, W, F>), dim3(grid), dim3(512), sm, stream, *a);          \
         return (int)hipGetLastError();                                                              \
     }
+#define FWD_CASE(CT, W) FWD_CASE_F(CT, W, true) FWD_CASE_F(CT, W, false)
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t stream) {
     if (grid <= 0) return 0;
+    bool fast = a->K % KT == 0 && aligned16(a->W);
+    for (int s = 0; s < 2; ++s)
+        if (a->seg[s].rows > 0) fast = fast && a->seg[s].ld % 4 == 0 && aligned16(a->seg[s].feats);
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(1, 8) FWD_CASE(2, 8) FWD_CASE(4, 8)
     return (int)hipErrorInvalidValue;
 }
 
 int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream) {
     if (g->M <= 0 || g->N <= 0) return 0;
-    dim3 grid((g->N + GBN - 1) / GBN, (g->M + GBM - 1) / GBM, splits);
-    if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_f32<0, 0>), grid, dim3(256), 0, stream, *g);
-    else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_f32<0, 1>), grid, dim3(256), 0, stream, *g);
-    else if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_f32<1, 1>), grid, dim3(256), 0, stream, *g);
-    else return (int)hipErrorInvalidValue;
-    return (int)hipGetLastError();
+    // 64x64 tiles when the 128x128 grid would leave most of the 256 CUs with a single 4-wave workgroup
+    long long wg128 = (long long)((g->N + 127) / 128) * ((g->M + 127) / 128) * splits;
+    const char* e = getenv("UMLH_F32_TM");
+    const int tm = e ? atoi(e) : (wg128 < 768 ? 1 : 2);
+    const int t = 64 * tm;
+    dim3 grid((g->N + t - 1) / t, (g->M + t - 1) / t, splits);
+#define GEMM_CASE(A_, B_, T_) if (ta == A_ && tb == B_ && tm == T_) { hipLaunchKernelGGL((gemm_f32<A_, B_, T_>), grid, dim3(256), 0, stream, *g); return (int)hipGetLastError(); }
+    GEMM_CASE(0, 0, 1) GEMM_CASE(0, 0, 2) GEMM_CASE(0, 1, 1) GEMM_CASE(0, 1, 2) GEMM_CASE(1, 1, 1) GEMM_CASE(1, 1, 2)
+    return (int)hipErrorInvalidValue;
 }
 
 int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long long slab_stride, long long n,
