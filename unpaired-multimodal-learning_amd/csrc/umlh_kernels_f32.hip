@@ -53,9 +53,11 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     constexpr int NPW = (CPAD * 4 + 511) / 512;     // float4 pieces of W per thread
     constexpr int NPX = (TS * 4 + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ws = smem;                     // [KT][LDW]
-    float* Xs = Ws + KT * LDW;            // [KT][LDX]
-    float* red = Xs + KT * LDX;           // [WC][TS][4]
+    // two LDS buffers of the (W, X) K-chunk: chunk c+1 is written while chunk c feeds the MFMAs, one
+    // barrier per chunk (the 64-cycle fp32 MFMAs of the partner wave cover the ds_write_b32 stream)
+    constexpr int BUF = KT * (LDW + LDX);
+    float* Ws0 = smem;                    // [2][KT][LDW] then [KT][LDX]
+    float* red = smem + 2 * BUF;          // [WC][TS][4]
     float* red2 = red + WC * TS * 4;      // [WS][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
             else xreg[q] = xsrc[q] ? load4_guard(xsrc[q] + k, K - k, vecX) : f32x4v{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) {
+        float* Ws = Ws0 + buf * BUF;
+        float* Xs = Ws + KT * LDW;
 #pragma unroll
         for (int q = 0; q < NPW; ++q) {
             int p = tid + 512 * q;
@@ -141,14 +145,9 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
             }
         }
     };
-
-    gload(0);
-    for (int k0 = 0; k0 < K; k0 += KT) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (FAST) gload(min(k0 + KT, K - KT));          // branch-free: the last prefetch re-loads the last chunk
-        else if (k0 + KT < K) gload(k0 + KT);
+    auto compute = [&](int buf) {
+        const float* Ws = Ws0 + buf * BUF;
+        const float* Xs = Ws + KT * LDW;
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
             const int krow = 2 * kk + h;
@@ -159,6 +158,21 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
                 acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[ct], 0, 0, 0);
             }
         }
+    };
+
+    // chunk c lives in buffer c & 1; registers hold chunk c+1 while chunk c is computed
+    gload(0);
+    lstore(0);
+    if (FAST) gload(min(KT, K - KT)); else if (KT < K) gload(KT);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += KT) {
+        if (k0 + KT < K) lstore(buf ^ 1);                // chunk c+1 -> the other buffer (its readers passed the last barrier)
+        if (FAST) gload(min(k0 + 2 * KT, K - KT));       // branch-free: tail prefetches re-load the last chunk
+        else if (k0 + 2 * KT < K) gload(k0 + 2 * KT);
+        compute(buf);
+        __syncthreads();
+        buf ^= 1;
     }
 
     // ---------------- epilogue: softmax cross entropy on the register tile ----------------
@@ -279,8 +293,9 @@ constexpr int GKIDS = 4096;   // reduction rows per split whose row ids fit the 
 template <int TA, int TB, int TM>
 __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
     constexpr int GBM = 64 * TM, GBN = 64 * TM, GLD = GBM + 4;
-    __shared__ __attribute__((aligned(16))) float As[KT * GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[KT * GLD];
+    // double-buffered K-chunks: one barrier per chunk, LDS writes of chunk c+1 overlap the MFMAs of chunk c
+    __shared__ __attribute__((aligned(16))) float As2[2][KT * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs2[2][KT * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
@@ -386,7 +401,9 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
             }
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) {
+        float* As = As2[buf];
+        float* Bs = Bs2[buf];
 #pragma unroll
         for (int q = 0; q < TM; ++q) {
             int p = tid + 256 * q;
@@ -409,12 +426,9 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
         }
     };
 
-    if (kb < ke) gload(kb);
-    for (int k0 = kb; k0 < ke; k0 += KT) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (k0 + KT < ke) gload(k0 + KT);
+    auto compute = [&](int buf) {
+        const float* As = As2[buf];
+        const float* Bs = Bs2[buf];
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
             const int krow = 2 * kk + h;
@@ -429,6 +443,20 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+    };
+    if (kb < ke) {
+        gload(kb);
+        lstore(0);
+        if (kb + KT < ke) gload(kb + KT);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += KT) {
+        if (k0 + KT < ke) lstore(buf ^ 1);               // chunk c+1 (in registers) -> the other buffer
+        if (k0 + 2 * KT < ke) gload(k0 + 2 * KT);
+        compute(buf);
+        __syncthreads();
+        buf ^= 1;
     }
 
     float* out = g.out + (size_t)blockIdx.z * g.slab_stride;
@@ -688,7 +716,7 @@ int umlh_f32_fwd_config(int C, int* ctw, int* wc) {
 
 static size_t fwd_smem_bytes(int ctw, int wc) {
     int ws = 8 / wc, cpad = 32 * ctw * wc, ts = 32 * ws;
-    return sizeof(float) * (size_t)(KT * (cpad + 4) + KT * (ts + 4) + wc * ts * 4 + ws * 4 + 16);
+    return sizeof(float) * (size_t)(2 * KT * (cpad + 4 + ts + 4) + wc * ts * 4 + ws * 4 + 16);
 }
 
 #define FWD_CASE_F(CT, W, F)                                                                        \
