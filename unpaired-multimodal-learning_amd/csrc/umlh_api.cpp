@@ -28,17 +28,6 @@ int umlh_launch_w_shadow(const float* w, void* dst, int C, int K, int cpad, hipS
 int umlh_launch_iota(long long* dst, long long n, hipStream_t stream);
 }
 
-// argument blocks of the bf16 kernels (layout must match umlh_kernels_bf16.hip)
-typedef unsigned short u16;
-struct SegDescB {
-    const u16* feats; const int64_t* feat_index; const int64_t* labels; const int64_t* label_index;
-    const float* scale_ptr; int rows, ld, col0, blk0; float w_over_rows;
-};
-struct FwdArgsB { SegDescB seg[2]; const u16* W; int C, K; u16* dzt; int crows; float* partials; int dbg; int learn; };
-struct DwArgsB {
-    const u16* A; const u16* B; const int64_t* k_rows; int ldb; const u16* B2; const int64_t* k_rows2; int ldb2;
-    float* out; const u16* zeros; int dbg; int M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit; long long slab_stride;
-};
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, hipStream_t stream);

@@ -14,7 +14,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
@@ -76,38 +75,6 @@ __global__ __launch_bounds__(256) void w_shadow_kernel(const float* __restrict__
     }
     *reinterpret_cast<u32x4*>(dst + piece * 8) = o;
 }
-
-struct SegDescB {
-    const u16*     feats;        // [*, ld] bf16
-    const int64_t* feat_index;
-    const int64_t* labels;
-    const int64_t* label_index;
-    const float*   scale_ptr;
-    int   rows, ld, col0, blk0;
-    float w_over_rows;
-};
-
-struct FwdArgsB {
-    SegDescB seg[2];
-    const u16* W;                // bf16 fragment-major shadow of the head weight (w_shadow_kernel)
-    int   C, K;
-    u16*  dzt;                   // bf16 dZ^T, column-chunk-major [cols/64][crows][64]; NULL = eval
-    int   crows;                 // class rows per column chunk (C rounded up to 128)
-    float* partials;
-    int   dbg;                   // timing-only ablations: 1 = main loop only, 2 = epilogue only
-    int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
-};
-
-struct DwArgsB {
-    const u16* A;                // dZ^T bf16, column-chunk-major [K/64][lda=crows][64]
-    const u16* B;  const int64_t* k_rows;  int ldb;     // image-side feature rows
-    const u16* B2; const int64_t* k_rows2; int ldb2;    // text-side feature rows (k >= k_switch)
-    float* out;                  // fp32 slabs [splits][M][ldo]
-    const u16* zeros;            // >= 16 B of zeros (source of masked loads)
-    int   dbg;                   // timing-only ablations: bit0 = no A traffic, bit1 = no F traffic
-    int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit;
-    long long slab_stride;
-};
 
 // --------------------------------------------------------------------------- //
 // fused forward + cross entropy, bf16 operands
