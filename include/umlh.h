@@ -170,6 +170,9 @@ int  umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_stre
 int  umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
                     const umlh_hyper_t* hyper, void* stream);
 int  umlh_grad_buffer(umlh_handle_t h, float** device_ptr, uint64_t* n_floats);
+/* Diagnostic builds only (UMLH_DBG_FWD=9): per-workgroup cycle stamps of the forward kernel,
+ * a region of the workspace no other code reads. */
+int  umlh_debug_buffer(umlh_handle_t h, void** device_ptr, uint64_t* n_bytes);
 int  umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hyper, float* scalars_out, void* stream);
 
 /* validate() inner loop for one batch (finetune.py:295-308): logits -> argmax ->

@@ -46,7 +46,7 @@ static int fail(int code, const char* fmt, ...) {
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 struct Layout {                 // workspace partition, in floats from the base
-    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, iota, zeros, total;
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, iota, zeros, dbg, total;
     int rcap_img, rcap_txt, ldz;     // padded row capacities
     int scap_head, scap_proj;        // split-K slab capacities
     long long n_head, n_proj;        // parameter counts
@@ -92,6 +92,7 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     L.w16 = take(c.precision == UMLH_PREC_BF16 ? 1024LL * c.d_shared / 2 : 0);   // bf16 chunk-major shadow of w_head (<= 1024 class rows)
     L.iota = take(c.precision == UMLH_PREC_BF16 ? 2LL * (L.rcap_img > L.rcap_txt ? L.rcap_img : L.rcap_txt) : 0);   // int64 0..cap-1
     L.zeros = take(64);
+    L.dbg = take((long long)L.max_blocks * 128);         // diagnostic stamps: [blocks][8 waves][8] u64
     L.total = off;
     return true;
 }
@@ -424,6 +425,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         fb.partials = ws(h, L.partials);
         { const char* e = getenv("UMLH_DBG_FWD"); fb.dbg = e ? atoi(e) : 0; }
         fb.learn = c.learnable_temp;
+        fb.stamps = fb.dbg == 9 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
         mark(h, 2, st);
         *n_slabs_head = 0; *n_slabs_proj = 0;
@@ -683,6 +685,13 @@ int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t*
     h->last_rows_img = img ? img->rows : 0;
     h->last_rows_txt = txt ? txt->rows : 0;
     mark(h, 5, st);
+    return UMLH_OK;
+}
+
+int umlh_debug_buffer(umlh_handle_t h, void** device_ptr, uint64_t* n_bytes) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_debug_buffer: handle not bound");
+    if (device_ptr) *device_ptr = ws(h, h->L.dbg);
+    if (n_bytes) *n_bytes = (uint64_t)h->L.max_blocks * 128 * sizeof(float);
     return UMLH_OK;
 }
 

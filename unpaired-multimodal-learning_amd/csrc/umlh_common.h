@@ -78,6 +78,7 @@ struct FwdArgsB {
     float* partials;
     int   dbg;                   // timing-only ablations: 1 = main loop only, 2 = epilogue only
     int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
+    unsigned long long* stamps;  // diagnostic build only (UMLH_DBG_FWD=9): [grid][8] s_memtime stamps of wave 0
 };
 
 struct DwArgsB {

@@ -98,13 +98,15 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     constexpr int UNION_BYTES = XT_BYTES > STAGE_BYTES ? XT_BYTES : STAGE_BYTES;
     unsigned* dzstage = reinterpret_cast<unsigned*>(smem_raw);   // aliases Xt: used only after the last barrier of pass 2
     float* red = reinterpret_cast<float*>(smem_raw + UNION_BYTES);   // [WS][WC][32][4]
-    float* red2 = red + 8 * 32 * 4;                              // [WS][4]
+    float* red2 = red + 8 * 32 * 8;                              // [WS][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave % WC, ws = wave / WC;
     const int h = lane >> 5, l31 = lane & 31;
     const int sidx = (int)blockIdx.x >= a.seg[1].blk0 ? 1 : 0;
     const SegDescB& sg = a.seg[sidx];
+#define STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    STAMP(0);
     const int row0 = ((int)blockIdx.x - sg.blk0) * TS;
     const int C = a.C, K = a.K;
 
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct) ring[d][ct] = wfrag(min(d, nks - 1), ct);
 
+    STAMP(1);
     for (int kb0 = 0; kb0 < ((a.dbg == 2 || a.dbg == 5) ? 0 : K); kb0 += XK) {
         const int kbw = min(XK, K - kb0);                        // multiple of 128
         // ---- stage the X block: global -> registers -> LDS ----
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         }
     }
 
+    STAMP(2);
     if (a.dbg == 1 || a.dbg == 5) {                    // ablation: keep the accumulators live, skip the epilogue
         float t = 0.f;
 #pragma unroll
@@ -250,21 +254,12 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
             int omi = __shfl_xor(mi, 32);
             if (omk > mk || (omk == mk && omi < mi)) { mk = omk; mi = omi; }
         }
-        if (WC > 1) {
-            __syncthreads();
-            if (h == 0) { red[((ws * WC + wc) * 32 + l31) * 4 + 0] = mk; red[((ws * WC + wc) * 32 + l31) * 4 + 1] = __int_as_float(mi); }
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < WC; ++w) {
-                float omk = red[((ws * WC + w) * 32 + l31) * 4 + 0];
-                int omi = __float_as_int(red[((ws * WC + w) * 32 + l31) * 4 + 1]);
-                if (omk > mk || (omk == mk && omi < mi)) { mk = omk; mi = omi; }
-            }
-        }
+        STAMP(6);
         if (a.dbg == 4) { bl += mk; continue; }          // ablation: argmax pass only
-        const float mx = mk * sgn * scale;               // max scaled logit ( = |scale| * mk )
-        const float mxl = mx * LOG2E;
-        // ---- pass 2: e = exp(z - max), sum, label logit ----
+        // ---- pass 2: e = exp(z - WAVE-LOCAL max), sums, label logit.  The waves' partial results are
+        // merged afterwards with the online-softmax rule (one LDS exchange instead of max-then-sum) ----
+        const float asl2 = sgn * sl2;                    // |scale| * log2(e)
+        const float mwl = mk * asl2;                     // wave-local max scaled logit, in log2 units
         float sec[CTW], serwc[CTW], rawyc[CTW];
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct) {
@@ -275,7 +270,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
             for (int i = 0; i < 16; ++i) {
                 const int cls = cbase + acc_row(i, h);
                 const float raw = acc[ct][st][i];
-                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(raw, sl2, -mxl));
+                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(raw, sl2, -mwl));
                 if (!full) e = cls < C ? e : 0.f;
                 sec[ct] += e;
                 if (learn) serwc[ct] = __builtin_fmaf(e, raw, serwc[ct]);
@@ -289,20 +284,37 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         se += __shfl_xor(se, 32);
         serw += __shfl_xor(serw, 32);
         rawy += __shfl_xor(rawy, 32);
+        STAMP(7);
+        float fown = 1.f;                                // exp(own wave max - global max)
         if (WC > 1) {
             __syncthreads();
             if (h == 0) {
-                float* d = red + ((ws * WC + wc) * 32 + l31) * 4;
-                d[0] = se; d[1] = serw; d[2] = rawy;
+                float* d = red + ((ws * WC + wc) * 32 + l31) * 8;
+                d[0] = mk; d[1] = __int_as_float(mi); d[2] = se; d[3] = serw; d[4] = rawy;
             }
             __syncthreads();
+            const float mown = mk;
+#pragma unroll
+            for (int w = 0; w < WC; ++w) {
+                const float* d = red + ((ws * WC + w) * 32 + l31) * 8;
+                const float omk = d[0];
+                const int omi = __float_as_int(d[1]);
+                if (omk > mk || (omk == mk && omi < mi)) { mk = omk; mi = omi; }
+            }
             se = serw = rawy = 0.f;
 #pragma unroll
             for (int w = 0; w < WC; ++w) {
-                const float* d = red + ((ws * WC + w) * 32 + l31) * 4;
-                se += d[0]; serw += d[1]; rawy += d[2];
+                const float* d = red + ((ws * WC + w) * 32 + l31) * 8;
+                // a wave whose classes are all masked has max -inf and zero sums: exp2(-inf) = 0
+                const float f = __builtin_amdgcn_exp2f((d[0] - mk) * asl2);
+                se = __builtin_fmaf(d[2], f, se);
+                serw = __builtin_fmaf(d[3], f, serw);
+                rawy += d[4];
             }
+            fown = __builtin_amdgcn_exp2f((mown - mk) * asl2);
         }
+        const float mx = mk * sgn * scale;               // max scaled logit ( = |scale| * mk )
+        STAMP(3);
         const float zy = rawy * scale;
         // ---- pass 3: dZ^T (bf16, two columns per dword) ----
         if (a.dzt != nullptr && a.dbg != 3 && a.dbg != 4) {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
             // register of a pair, receives the neighbour's copy of it by a DPP quad swap and stores
             // ONE packed dword (even lane: class row c0, odd lane: class row c0+1).
             const float coef = valid ? sg.w_over_rows * scale : 0.f;
-            const float ic = coef / se;                   // dZ = e*ic - onehot*coef
+            const float ic = coef * fown / se;            // dZ = e_local * exp(m_wave - m) / S * coef - onehot*coef
             const bool odd = lane & 1;
             // dword index of (class row = 4h + odd, this column pair) inside dZ^T's chunk-major layout
             if (WC == 1 && st == 0) __syncthreads();       // staging aliases the X tile: every wave must have left the main loop
@@ -355,6 +367,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
                 if (cls < C) *reinterpret_cast<u32x4*>(gbase + (size_t)cls * 64 + (lane & 3) * 8) = v;
             }
         }
+        STAMP(4);
         if (wc == 0 && h == 0 && valid) {
             bl += __logf(se) + mx - zy;
             bc += (mi == lab) ? 1.f : 0.f;
@@ -376,6 +389,8 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         float* o = a.partials + (size_t)blockIdx.x * 4;
         o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
     }
+    STAMP(5);
+#undef STAMP
 }
 
 // --------------------------------------------------------------------------- //
@@ -571,7 +586,7 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
     int ws = 8 / wc, ts = 32 * stw * ws;
     int xk = ws <= 2 ? 512 : (ws == 4 ? 256 : 128);
     size_t xt = (size_t)ts * (xk + 8) * 2, stage = (size_t)8 * ctw * 32 * 64;
-    return (xt > stage ? xt : stage) + sizeof(float) * (size_t)(8 * 32 * 4 + ws * 4 + 16);
+    return (xt > stage ? xt : stage) + sizeof(float) * (size_t)(8 * 32 * 8 + ws * 4 + 16);
 }
 
 #define FWDB_CASE(CT, W, S)                                                                          \

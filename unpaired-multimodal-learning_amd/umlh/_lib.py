@@ -24,7 +24,7 @@ EXPORTS = ["umlh_last_error", "umlh_version", "umlh_workspace_bytes", "umlh_crea
            "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
            "umlh_train_steps", "umlh_seq_mse_forward", "umlh_seq_mse_backward",
-           "umlh_random_permutation"]
+           "umlh_random_permutation", "umlh_debug_buffer"]
 
 
 class UmlhError(RuntimeError):
@@ -121,6 +121,7 @@ def load_library():
     lib.umlh_seq_mse_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.umlh_seq_mse_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.umlh_random_permutation.argtypes = [i64, u64, vp, vp]
+    lib.umlh_debug_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.umlh_profile_enable.argtypes = [vp, C.c_int]
     lib.umlh_profile_read.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:
