@@ -9,6 +9,7 @@
 //   fwd_ce_bf16    fused  X W^T * scale -> softmax-CE -> dZ^T (bf16), loss / top-1 / dscale
 //   dw_bf16        dW = dZ^T F with the k-strided operand read through ds_read_b64_tr_b16
 #include "umlh_common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     constexpr int NPX = (TS * (XK / 8)) / 512;                   // 16-B pieces of the X block per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xt = reinterpret_cast<u16*>(smem_raw);                  // [TS][XRS]
-    constexpr int STAGE_BYTES = 8 * CTW * 32 * 64;               // dZ staging: 8 waves x [CTW*32 rows][64 B]
+    constexpr int STAGE_BYTES = 8 * CTW * 32 * 80;               // dZ staging: 8 waves x [CTW*32 rows][80 B (64 data + 16 pad)]
     constexpr int XT_BYTES = TS * XRS * 2;
     constexpr int UNION_BYTES = XT_BYTES > STAGE_BYTES ? XT_BYTES : STAGE_BYTES;
     unsigned* dzstage = reinterpret_cast<unsigned*>(smem_raw);   // aliases Xt: used only after the last barrier of pass 2
@@ -170,7 +171,12 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         // ---- k-steps of this block ----
         const int ks0 = kb0 / 16, nst = kbw / 16;                // nst is a multiple of PD
         const u16* xrow = Xt + (ws * 32 * STW + l31) * XRS + h * 8;
-        for (int s = 0; s < nst; s += PD) {
+        // one group = PD k-steps; REFILL = the slot just consumed is reloaded PD k-steps ahead.  The
+        // very last group of the kernel has nothing left to fetch: issuing clamped refills there cost
+        // PD/nks of extra L2->CU traffic on the stream that bounds this kernel, and made the epilogue
+        // wait on them before it could reuse the ring registers.
+        auto kgroup = [&](int s, auto refill) {
+            constexpr bool REFILL = decltype(refill)::value;
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
                 bf16x8 b[STW];
@@ -182,17 +188,23 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 #pragma unroll
                     for (int st = 0; st < STW; ++st)
                         acc[ct][st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[d][ct], b[st], acc[ct][st], 0, 0, 0);
-                const int nxt = min(ks0 + s + d + PD, nks - 1);  // refill this slot PD k-steps ahead
+                if constexpr (REFILL) {
+                    const int nxt = ks0 + s + d + PD;
 #pragma unroll
-                for (int ct = 0; ct < CTW; ++ct) ring[d][ct] = wfrag(nxt, ct);
+                    for (int ct = 0; ct < CTW; ++ct) ring[d][ct] = wfrag(nxt, ct);
+                }
                 // pin the emitted order per k-step: B read, its MFMAs, then the slot's refill loads
                 // (left alone, hipcc sinks all refills to the end of the group, which leaves the
                 // next group's first fragment zero time to arrive)
                 __builtin_amdgcn_sched_group_barrier(0x100, STW, 0);        // B reads
                 __builtin_amdgcn_sched_group_barrier(0x008, CTW * STW, 0);  // MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x020, CTW, 0);    // CTW VMEM reads
+                if constexpr (REFILL) __builtin_amdgcn_sched_group_barrier(0x020, CTW, 0);    // CTW VMEM reads
             }
-        }
+        };
+        const bool last_block = kb0 + XK >= K;
+        const int nfull = last_block ? nst - PD : nst;
+        for (int s = 0; s < nfull; s += PD) kgroup(s, std::true_type{});
+        if (last_block) kgroup(nst - PD, std::false_type{});
     }
 
     STAMP(2);
@@ -208,82 +220,118 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         return;
     }
     // ---------------- epilogue (per 32-sample tile of this wave) ----------------
-    // VALU-bound (64 logits per lane per tile): every pass is kept to a few ops per element --
-    // the max/argmax pass compares RAW accumulators (sign of the scale applied once), exp is one
-    // fma + v_exp_f32 (base-2, scale*log2e folded), dZ packs two columns per dword with a DPP swap
-    // and v_cvt_pk_bf16_f32, stores use a per-lane base + compile-time offsets.
+    // VALU-bound (64 logits per lane per tile), so every pass is kept to very few instructions per
+    // element and free of per-element class masks / sign selects:
+    //   * the scale's sign and the padded classes of a partial tile are folded into the accumulators
+    //     once, in wave-uniform branches that are almost never taken;
+    //   * max = v_max3 chains; first arg-max = (value == max) overwrite in descending order with the
+    //     register number as an inline constant; label logit = select tree on the bits of the label's
+    //     register number (63 selects instead of 64 compares + 64 selects);
+    //   * exp / sums / dZ scaling work on register PAIRS (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32);
+    //   * dZ is packed by v_cvt_pk_bf16_f32 and staged in LDS; the one-hot term is patched into the
+    //     staged tile by the one lane that owns the label element.
+    static_assert(CTW == 1 || CTW == 2 || CTW == 4, "label select tree needs a power-of-two CTW");
+    constexpr int NREG = CTW * 16;                       // logits per lane per sample tile
+    constexpr int ZRS = 20;                              // staged dZ row stride (dwords): 64 B of data + 16 B pad
     const float scale = *sg.scale_ptr;
-    const float sgn = scale < 0.f ? -1.f : 1.f;          // argmax(scale*raw) = argmax(sgn*raw)
+    const float sgn = scale < 0.f ? -1.f : 1.f;
     const float LOG2E = 1.4426950408889634f;
-    const float sl2 = scale * LOG2E;
-    const float NEG_INF = -__builtin_huge_valf();
-    const bool learn = a.learn != 0;
-    float bl = 0.f, bc = 0.f, bg = 0.f;            // block sums: loss, correct, dscale
+    const float ascale = __builtin_fabsf(scale);
+    // exponent slope; the floor only matters for scale == 0, where it keeps padded classes at e = 0
+    const float asl2 = __builtin_fmaxf(ascale * LOG2E, 1e-20f);
+    const float MASKED = -1e30f;
+    if (scale < 0.f) {                                   // argmax/softmax of scale*raw == those of |scale| * (-raw)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int st = 0; st < STW; ++st)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ct][st][i] = -acc[ct][st][i];
+    }
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) {
+        const int cbase = (wc * CTW + ct) * 32;
+        if (cbase + 32 > C) {                            // wave-uniform: only the tile that straddles C
+#pragma unroll
+            for (int st = 0; st < STW; ++st)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    acc[ct][st][i] = cbase + acc_row(i, h) < C ? acc[ct][st][i] : MASKED;
+        }
+    }
+    const int wave_c0 = wc * CTW * 32;                   // first class of this wave
+    float bl = 0.f, bc = 0.f, bg = 0.f;                  // block sums: loss, correct, dscale
 #pragma unroll
     for (int st = 0; st < STW; ++st) {
         const int smp = ws * 32 * STW + st * 32 + l31;
         const int r = row0 + smp;
         const bool valid = r < sg.rows;
         const int lab = valid ? labs[st] : -1;
-        // ---- pass 1: first arg-max of the (sign-corrected) raw logits ----
-        // one independent (max, index) chain per class tile: a single 64-long dependent chain would be
-        // latency-bound with only two waves per SIMD
+        // ---- pass 1: max over this lane's logits (independent chain per class tile) ----
         float mkc[CTW];
-        int mic[CTW];
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct) {
-            const int cbase = (wc * CTW + ct) * 32;
-            const bool full = cbase + 32 <= C;           // wave-uniform
-            mkc[ct] = NEG_INF;
-            mic[ct] = 0x7fffffff;
+            mkc[ct] = acc[ct][st][0];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int cls = cbase + acc_row(i, h);
-                float key = sgn > 0.f ? acc[ct][st][i] : -acc[ct][st][i];
-                if (!full) key = cls < C ? key : NEG_INF;
-                if (key > mkc[ct]) { mkc[ct] = key; mic[ct] = cls; }
-            }
+            for (int i = 1; i < 16; ++i) mkc[ct] = __builtin_fmaxf(mkc[ct], acc[ct][st][i]);
         }
         float mk = mkc[0];
-        int mi = mic[0];
 #pragma unroll
-        for (int ct = 1; ct < CTW; ++ct)                 // ascending class order: strict > keeps the first
-            if (mkc[ct] > mk) { mk = mkc[ct]; mi = mic[ct]; }
+        for (int ct = 1; ct < CTW; ++ct) mk = __builtin_fmaxf(mk, mkc[ct]);
+        mk = __builtin_fmaxf(mk, __shfl_xor(mk, 32));    // max over the wave's CTW*32 classes of this sample
+        // ---- label logit: register number = (tile, i) with i&3 = row&3, i>>2 = row>>3, h = (row>>2)&1 ----
+        const int rel = lab - wave_c0;                   // label relative to the wave's classes
+        const bool mine = rel >= 0 && rel < CTW * 32 && ((rel >> 2) & 1) == h;
+        float rawy;
         {
-            float omk = __shfl_xor(mk, 32);
-            int omi = __shfl_xor(mi, 32);
-            if (omk > mk || (omk == mk && omi < mi)) { mk = omk; mi = omi; }
+            const int reg = (rel & 3) | ((rel >> 3) & 3) << 2 | (rel >> 5) << 4;
+            float t[NREG];
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[ct * 16 + i] = acc[ct][st][i];
+#pragma unroll
+            for (int bit = 0, n = NREG; n > 1; ++bit, n >>= 1) {
+                const bool up = (reg >> bit) & 1;
+#pragma unroll
+                for (int j = 0; j < n / 2; ++j) t[j] = up ? t[2 * j + 1] : t[2 * j];
+            }
+            rawy = mine ? t[0] : 0.f;
         }
+        rawy += __shfl_xor(rawy, 32);                    // both lanes of the sample: label logit or 0
         STAMP(6);
-        if (a.dbg == 4) { bl += mk; continue; }          // ablation: argmax pass only
-        // ---- pass 2: e = exp(z - WAVE-LOCAL max), sums, label logit.  The waves' partial results are
+        if (a.dbg == 4) { bl += mk + rawy; continue; }   // ablation: max + label passes only
+        // ---- pass 2: first arg-max, e = exp(z - WAVE-LOCAL max), sums.  The waves' partial results are
         // merged afterwards with the online-softmax rule (one LDS exchange instead of max-then-sum) ----
-        const float asl2 = sgn * sl2;                    // |scale| * log2(e)
-        const float mwl = mk * asl2;                     // wave-local max scaled logit, in log2 units
-        float sec[CTW], serwc[CTW], rawyc[CTW];
+        // wave-local max scaled logit, in log2 units.  A wave whose classes are ALL padding has
+        // max = MASKED: keep its exponent base at 0 so every e underflows to 0 (with the base at
+        // MASKED*asl2 the fma's rounding residual, ~1e24, would overflow exp2 instead).
+        const float mwl = wave_c0 >= C ? 0.f : mk * asl2;
+        int first = NREG;                                // lowest register number holding the max
+        f32x2v se2 = {0.f, 0.f}, serw2 = {0.f, 0.f};
+        const f32x2v sl2v = {asl2, asl2}, nmwl = {-mwl, -mwl};
 #pragma unroll
-        for (int ct = 0; ct < CTW; ++ct) {
-            const int cbase = (wc * CTW + ct) * 32;
-            const bool full = cbase + 32 <= C;
-            sec[ct] = serwc[ct] = rawyc[ct] = 0.f;
+        for (int ct = CTW - 1; ct >= 0; --ct) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int cls = cbase + acc_row(i, h);
-                const float raw = acc[ct][st][i];
-                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(raw, sl2, -mwl));
-                if (!full) e = cls < C ? e : 0.f;
-                sec[ct] += e;
-                if (learn) serwc[ct] = __builtin_fmaf(e, raw, serwc[ct]);
-                rawyc[ct] = cls == lab ? raw : rawyc[ct];
-                acc[ct][st][i] = e;
+            for (int i = 14; i >= 0; i -= 2) {
+                const f32x2v raw = {acc[ct][st][i], acc[ct][st][i + 1]};
+                first = raw[1] == mk ? ct * 16 + i + 1 : first;
+                first = raw[0] == mk ? ct * 16 + i : first;
+                const f32x2v t = __builtin_elementwise_fma(raw, sl2v, nmwl);
+                const f32x2v e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                se2 += e;
+                serw2 = __builtin_elementwise_fma(e, raw, serw2);
+                acc[ct][st][i] = e[0];
+                acc[ct][st][i + 1] = e[1];
             }
         }
-        float se = 0.f, serw = 0.f, rawy = 0.f;
-#pragma unroll
-        for (int ct = 0; ct < CTW; ++ct) { se += sec[ct]; serw += serwc[ct]; rawy += rawyc[ct]; }
+        // class of register number n at this lane: tile n>>4, row (n&3) + 8*((n>>2)&3) + 4h
+        int mi = first < NREG ? wave_c0 + (first >> 4) * 32 + (first & 3) + 8 * ((first >> 2) & 3) + 4 * h : 0x7fffffff;
+        mi = min(mi, __shfl_xor(mi, 32));
+        float se = se2[0] + se2[1], serw = serw2[0] + serw2[1];
         se += __shfl_xor(se, 32);
         serw += __shfl_xor(serw, 32);
-        rawy += __shfl_xor(rawy, 32);
+        const float rawy_wave = rawy;
         STAMP(7);
         float fown = 1.f;                                // exp(own wave max - global max)
         if (WC > 1) {
@@ -305,7 +353,6 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 #pragma unroll
             for (int w = 0; w < WC; ++w) {
                 const float* d = red + ((ws * WC + w) * 32 + l31) * 8;
-                // a wave whose classes are all masked has max -inf and zero sums: exp2(-inf) = 0
                 const float f = __builtin_amdgcn_exp2f((d[0] - mk) * asl2);
                 se = __builtin_fmaf(d[2], f, se);
                 serw = __builtin_fmaf(d[3], f, serw);
@@ -313,43 +360,36 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
             }
             fown = __builtin_amdgcn_exp2f((mown - mk) * asl2);
         }
-        const float mx = mk * sgn * scale;               // max scaled logit ( = |scale| * mk )
+        const float mx = mk * ascale;                    // max scaled logit
         STAMP(3);
-        const float zy = rawy * scale;
-        // ---- pass 3: dZ^T (bf16, two columns per dword) ----
+        const float zy = rawy * ascale;                  // (sgn*raw_y) * |scale| = scale * raw_y
+        // ---- pass 3: dZ^T (bf16) ----
         if (a.dzt != nullptr && a.dbg != 3 && a.dbg != 4) {
-            // Lanes l, l^1 hold neighbouring columns of the same class rows: each lane keeps one
-            // register of a pair, receives the neighbour's copy of it by a DPP quad swap and stores
-            // ONE packed dword (even lane: class row c0, odd lane: class row c0+1).
             const float coef = valid ? sg.w_over_rows * scale : 0.f;
             const float ic = coef * fown / se;            // dZ = e_local * exp(m_wave - m) / S * coef - onehot*coef
-            const bool odd = lane & 1;
-            // dword index of (class row = 4h + odd, this column pair) inside dZ^T's chunk-major layout
             if (WC == 1 && st == 0) __syncthreads();       // staging aliases the X tile: every wave must have left the main loop
-            unsigned* dzs = dzstage + wave * (CTW * 32 * 16);                  // [CTW*32 rows][16 dwords]
-            const int lrow = lab - 4 * h - (odd ? 1 : 0);     // label relative to this lane's first row
+            unsigned* dzs = dzstage + wave * (CTW * 32 * ZRS);                 // [CTW*32 class rows][ZRS dwords]
+            u16* dzs16 = reinterpret_cast<u16*>(dzs);
+            const f32x2v icv = {ic, ic};
 #pragma unroll
             for (int ct = 0; ct < CTW; ++ct) {
-                const int cbase = (wc * CTW + ct) * 32;
-                const bool full = cbase + 32 <= C;
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
-                    const int rrow = cbase + (i & 3) + 8 * (i >> 2);          // class row of register i at h = 0, even lane
-                    // even lane keeps register i (row rrow+4h), odd lane keeps register i+1 (row rrow+4h+1)
-                    const float own_e = odd ? acc[ct][st][i + 1] : acc[ct][st][i];
-                    const float snd_e = odd ? acc[ct][st][i] : acc[ct][st][i + 1];
-                    // the neighbour needs MY value for ITS row: row of snd = rrow+4h+(odd?0:1)
-                    const int lab_s = lab - 4 * h - (odd ? 0 : 1);
-                    float own = __builtin_fmaf(own_e, ic, lrow == rrow ? -coef : 0.f);
-                    float snd = __builtin_fmaf(snd_e, ic, lab_s == rrow ? -coef : 0.f);
-                    // quad_perm [1,0,3,2]: swap with lane ^ 1
-                    float rcv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0xB1, 0xf, 0xf, true));
-                    bf16x2v pk = odd ? __builtin_convertvector(f32x2v{rcv, own}, bf16x2v)
-                                     : __builtin_convertvector(f32x2v{own, rcv}, bf16x2v);
-                    // stage in this wave's private LDS slice [class row][32 columns] (64-B rows)
-                    const int lr = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * h + (odd ? 1 : 0);   // row within the wave's CTW*32
-                    dzs[lr * 16 + (l31 >> 1)] = __builtin_bit_cast(unsigned, pk);
+                    // registers i, i+1 = class rows lr, lr+1 of this lane's sample column
+                    const f32x2v m = f32x2v{acc[ct][st][i], acc[ct][st][i + 1]} * icv;
+                    const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(m, bf16x2v));
+                    const int lr = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    dzs16[lr * (2 * ZRS) + l31] = (u16)(pk & 0xffffu);
+                    dzs16[(lr + 1) * (2 * ZRS) + l31] = (u16)(pk >> 16);
                 }
+            }
+            // one-hot term: the label element of this sample lives in exactly one wave; its h = 0 lane
+            // recomputes e from the label logit (same fma + exp2 as pass 2) and overwrites the staged value
+            if (h == 0 && rel >= 0 && rel < CTW * 32) {
+                const float ey = __builtin_amdgcn_exp2f(__builtin_fmaf(rawy_wave, asl2, -mwl));
+                const f32x2v v = {__builtin_fmaf(ey, ic, -coef), 0.f};
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+                dzs16[rel * (2 * ZRS) + l31] = (u16)(pk & 0xffffu);
             }
             // wave-local transpose done (same wave wrote and reads: program order + lgkmcnt suffice).
             // Each lane now stores 16 B = 8 columns of one class row: 16 rows x 64 B per instruction
@@ -362,16 +402,17 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 #pragma unroll
             for (int it = 0; it < CTW * 2; ++it) {
                 const int lr = it * 16 + (lane >> 2);                           // row within the wave's class range
-                const int cls = wc * CTW * 32 + lr;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(dzs + lr * 16 + (lane & 3) * 4);
+                const int cls = wave_c0 + lr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(dzs + lr * ZRS + (lane & 3) * 4);
                 if (cls < C) *reinterpret_cast<u32x4*>(gbase + (size_t)cls * 64 + (lane & 3) * 8) = v;
             }
+            if (STW > 1) __builtin_amdgcn_wave_barrier();                      // next tile reuses the staging slice
         }
         STAMP(4);
         if (wc == 0 && h == 0 && valid) {
             bl += __logf(se) + mx - zy;
             bc += (mi == lab) ? 1.f : 0.f;
-            bg += serw / se - rawy;
+            bg += sgn * (serw / se - rawy);
         }
     }
 #pragma unroll
@@ -585,7 +626,7 @@ int umlh_bf16_fwd_ts(int wc, int stw) { return 32 * stw * (8 / wc); }
 static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
     int ws = 8 / wc, ts = 32 * stw * ws;
     int xk = ws <= 2 ? 512 : (ws == 4 ? 256 : 128);
-    size_t xt = (size_t)ts * (xk + 8) * 2, stage = (size_t)8 * ctw * 32 * 64;
+    size_t xt = (size_t)ts * (xk + 8) * 2, stage = (size_t)8 * ctw * 32 * 80;
     return (xt > stage ? xt : stage) + sizeof(float) * (size_t)(8 * 32 * 8 + ws * 4 + 16);
 }
 
