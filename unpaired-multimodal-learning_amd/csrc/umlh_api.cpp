@@ -459,6 +459,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         g.k_chunk = chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
         g.nsplit = splits;
         { const char* e = getenv("UMLH_DBG_DW"); g.dbg = e ? atoi(e) : 0; }
+        if (g.dbg >= 16) { g.dbg -= 16; g.stamps = reinterpret_cast<unsigned long long*>(ws(h, L.dbg)); }   // +16: cycle stamps
         HIPCHK(umlh_bf16_launch_dw(&g, splits, st), "dw_bf16");
         *n_slabs_head = splits;
         mark(h, 3, st);

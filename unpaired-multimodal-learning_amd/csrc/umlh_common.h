@@ -90,6 +90,7 @@ struct DwArgsB {
     int   dbg;                   // timing-only ablations: bit0 = no A traffic, bit1 = no F traffic
     int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit;
     long long slab_stride;
+    unsigned long long* stamps;  // diagnostics (UMLH_DBG_DW=16+bits): [blocks][8 waves][8] cycle stamps, else NULL
 };
 
 struct OptArgs {

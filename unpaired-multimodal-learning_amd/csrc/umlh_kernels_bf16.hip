@@ -240,6 +240,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     // exponent slope; the floor only matters for scale == 0, where it keeps padded classes at e = 0
     const float asl2 = __builtin_fmaxf(ascale * LOG2E, 1e-20f);
     const float MASKED = -1e30f;
+    const bool learn = a.learn != 0;
     if (scale < 0.f) {                                   // argmax/softmax of scale*raw == those of |scale| * (-raw)
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct)
@@ -334,30 +335,46 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         const float rawy_wave = rawy;
         STAMP(7);
         float fown = 1.f;                                // exp(own wave max - global max)
+        bool hit = mi == lab;                            // the wave-local first arg-max is the label
         if (WC > 1) {
-            __syncthreads();
+            // field-major exchange buffer red[ws][field][wave][32]: lanes read consecutive floats (no bank
+            // conflicts; the h = 1 half reads the same addresses as h = 0).  Fields: max, sum of exp
+            // (sign bit = "local arg-max is the label"), sum of exp*raw, label logit.
+            float* rb = red + ws * (4 * WC * 32) + l31;
+            if (st > 0) __syncthreads();                 // previous tile's records fully consumed
             if (h == 0) {
-                float* d = red + ((ws * WC + wc) * 32 + l31) * 8;
-                d[0] = mk; d[1] = __int_as_float(mi); d[2] = se; d[3] = serw; d[4] = rawy;
+                rb[(0 * WC + wc) * 32] = mk;
+                rb[(1 * WC + wc) * 32] = hit ? -se : se;
+                rb[(2 * WC + wc) * 32] = serw;
+                rb[(3 * WC + wc) * 32] = rawy;
             }
             __syncthreads();
             const float mown = mk;
+            float om[WC], os[WC];
+#pragma unroll
+            for (int w = 0; w < WC; ++w) { om[w] = rb[(0 * WC + w) * 32]; os[w] = rb[(1 * WC + w) * 32]; }
+            // global max; on ties the lowest wave (= lowest classes) wins, and its flag is the verdict
+            mk = om[0];
+            float win = os[0];
+#pragma unroll
+            for (int w = 1; w < WC; ++w) { win = om[w] > mk ? os[w] : win; mk = __builtin_fmaxf(mk, om[w]); }
+            hit = win < 0.f;
+            se = 0.f;
+            float fw[WC];
 #pragma unroll
             for (int w = 0; w < WC; ++w) {
-                const float* d = red + ((ws * WC + w) * 32 + l31) * 8;
-                const float omk = d[0];
-                const int omi = __float_as_int(d[1]);
-                if (omk > mk || (omk == mk && omi < mi)) { mk = omk; mi = omi; }
+                // a wave whose classes are all padding has max MASKED and zero sums: its factor underflows to 0
+                fw[w] = __builtin_amdgcn_exp2f((om[w] - mk) * asl2);
+                se = __builtin_fmaf(__builtin_fabsf(os[w]), fw[w], se);
             }
-            se = serw = rawy = 0.f;
+            serw = 0.f;
+            if (learn) {
 #pragma unroll
-            for (int w = 0; w < WC; ++w) {
-                const float* d = red + ((ws * WC + w) * 32 + l31) * 8;
-                const float f = __builtin_amdgcn_exp2f((d[0] - mk) * asl2);
-                se = __builtin_fmaf(d[2], f, se);
-                serw = __builtin_fmaf(d[3], f, serw);
-                rawy += d[4];
+                for (int w = 0; w < WC; ++w) serw = __builtin_fmaf(rb[(2 * WC + w) * 32], fw[w], serw);
             }
+            // the label logit sits in exactly one wave's record
+            const int wown = min(max(lab, 0) / (CTW * 32), WC - 1);
+            rawy = rb[(3 * WC + wown) * 32];
             fown = __builtin_amdgcn_exp2f((mown - mk) * asl2);
         }
         const float mx = mk * ascale;                    // max scaled logit
@@ -366,21 +383,25 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         // ---- pass 3: dZ^T (bf16) ----
         if (a.dzt != nullptr && a.dbg != 3 && a.dbg != 4) {
             const float coef = valid ? sg.w_over_rows * scale : 0.f;
-            const float ic = coef * fown / se;            // dZ = e_local * exp(m_wave - m) / S * coef - onehot*coef
+            const float ic = coef * fown * __builtin_amdgcn_rcpf(se);   // dZ = e_local * exp(m_wave - m) / S * coef - onehot*coef
             if (WC == 1 && st == 0) __syncthreads();       // staging aliases the X tile: every wave must have left the main loop
             unsigned* dzs = dzstage + wave * (CTW * 32 * ZRS);                 // [CTW*32 class rows][ZRS dwords]
             u16* dzs16 = reinterpret_cast<u16*>(dzs);
             const f32x2v icv = {ic, ic};
+            // v_cvt_pk gives (row lr, row lr+1) of ONE column; the staged tile wants two COLUMNS of one
+            // row per dword.  Lanes l, l^1 swap their packed pairs (DPP quad_perm [1,0,3,2]) and a byte
+            // permute picks: even lane -> row lr [own.lo, nbr.lo], odd lane -> row lr+1 [nbr.hi, own.hi].
+            const bool odd = lane & 1;
+            const unsigned psel = odd ? 0x03020706u : 0x05040100u;          // bytes 0-3 = own (S1), 4-7 = neighbour (S0)
+            unsigned* dzl = dzs + (4 * h + (odd ? 1 : 0)) * ZRS + (l31 >> 1);
 #pragma unroll
             for (int ct = 0; ct < CTW; ++ct) {
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
-                    // registers i, i+1 = class rows lr, lr+1 of this lane's sample column
                     const f32x2v m = f32x2v{acc[ct][st][i], acc[ct][st][i + 1]} * icv;
-                    const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(m, bf16x2v));
-                    const int lr = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    dzs16[lr * (2 * ZRS) + l31] = (u16)(pk & 0xffffu);
-                    dzs16[(lr + 1) * (2 * ZRS) + l31] = (u16)(pk >> 16);
+                    const unsigned own = __builtin_bit_cast(unsigned, __builtin_convertvector(m, bf16x2v));
+                    const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true);
+                    dzl[(ct * 32 + (i & 3) + 8 * (i >> 2)) * ZRS] = __builtin_amdgcn_perm(nbr, own, psel);
                 }
             }
             // one-hot term: the label element of this sample lives in exactly one wave; its h = 0 lane
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         STAMP(4);
         if (wc == 0 && h == 0 && valid) {
             bl += __logf(se) + mx - zy;
-            bc += (mi == lab) ? 1.f : 0.f;
+            bc += hit ? 1.f : 0.f;
             bg += sgn * (serw / se - rawy);
         }
     }
@@ -477,6 +498,8 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#define DSTAMP(i) do { if (g.stamps && lane == 0) g.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    DSTAMP(0);
 
     struct Stage { u32x4 a[2]; u32x4 f[2]; };
     Stage st[DNS];
@@ -565,24 +588,77 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
         ids[i] = valid ? (int)ip[kl] : DMASK;
     }
     __syncthreads();
+    DSTAMP(1);
 #pragma unroll
     for (int d = 0; d < DNS; ++d) gloadF(st[d], min(d, lastc));
     lstore(st[0], 0);                                   // chunk 0 -> buffer 0
     gload(st[0], min(DNS, lastc));
     __syncthreads();
+    DSTAMP(2);
     // iteration for chunk c (buffer c&1): stage chunk c+1 into the other buffer, refill its register
     // stage with chunk c+1+DNS, run the MFMAs of chunk c, one barrier.  DNS is even, so (c+1)&1 and
     // the stage index (c+1)%DNS are compile-time constants inside the unrolled body.
+    // Staging is interleaved with the MFMAs, one piece per k-step: {fragment reads, MFMA, ds_write of
+    // piece s of chunk c+1, MFMA, global load of piece s of chunk c+1+DNS}.  Issued as separate phases
+    // (all stores, all loads, then all MFMAs) the eight waves move in lockstep between barriers and the
+    // LDS-store transfer (13 cycles per ds_write_b128 per wave) is never hidden behind matrix work.
+    static_assert(DKT / 16 == 4, "one staging piece (a0, a1, f0, f1) per k-step");
+    auto store_piece = [&](const Stage& sg, int buf, int pc) {
+        const int q = pc & 1, pidx = tid + 512 * q;
+        if (pc < 2) *reinterpret_cast<u32x4*>(At[buf] + (pidx >> 3) * RSA + 8 * (pidx & 7)) = sg.a[q];
+        else        *reinterpret_cast<u32x4*>(Ft[buf] + (pidx >> 4) * RSF + 8 * (pidx & 15)) = sg.f[q];
+    };
+    auto load_piece = [&](Stage& sg, int c, int pc, const int (&rids)[2]) {
+        const int q = pc & 1;
+        const int k0 = kb + c * DKT;
+        if (pc < 2) {
+            const size_t achunk = (size_t)(k0 >> 6) * g.lda * 64;
+            const u16* ap = (k0 + a_col[q] < ke && !(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
+            sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
+        } else {
+            const bool seg2 = k0 >= g.k_switch;
+            const u16* fb = seg2 ? g.B2 : g.B;
+            const int ld = seg2 ? g.ldb2 : g.ldb;
+            const int rid = rids[q];
+            const u16* fp = (rid != DMASK && f_colok[q] && !(g.dbg & 2)) ? fb + (size_t)rid * ld + f_col[q] : g.zeros;
+            sg.f[q] = *reinterpret_cast<const u32x4*>(fp);
+        }
+    };
     for (int c = 0; c < ((g.dbg & 4) ? 0 : nchunks); c += DNS) {      // dbg bit2: skip the main loop (fixed-cost probe)
 #pragma unroll
         for (int d = 0; d < DNS; ++d) {
             const int nd = (d + 1) % DNS;
-            lstore(st[nd], (d + 1) & 1);              // (past the end: a harmless re-store of the last chunk)
-            gload(st[nd], min(c + d + 1 + DNS, lastc));
-            compute(d & 1);
+            const int buf = d & 1, nbuf = (d + 1) & 1;
+            const int cnext = min(c + d + 1 + DNS, lastc);            // (past the end: a harmless re-store of the last chunk)
+            const u16* a_frag = At[buf] + a_off;
+            const u16* f_frag = Ft[buf] + f_off;
+            const int rids[2] = {ids[cnext * DKT + f_row[0]], ids[cnext * DKT + f_row[1]]};
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // row ids of the chunk to fetch
+#pragma unroll
+            for (int ks = 0; ks < DKT / 16; ++ks) {
+                bf16x8 av[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(a_frag + i * 32 * RSA + ks * 16);
+                const u16* base = f_frag + ks * 16 * RSF;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * RSF));
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, v);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv, acc[0], 0, 0, 0);
+                store_piece(st[nd], nbuf, ks);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv, acc[1], 0, 0, 0);
+                load_piece(st[nd], cnext, ks, rids);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // fragment reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // ds_write of the staged piece
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // global load of the next piece
+            }
             __syncthreads();
         }
+        if (c < 3 * DNS) DSTAMP(3 + c / DNS);
     }
+    DSTAMP(6);
 
     float* out = g.out + (size_t)z * g.slab_stride;
     const int n = n0 + wn * 32 + l31;
@@ -595,6 +671,8 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
                 if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][e];
             }
     }
+    DSTAMP(7);
+#undef DSTAMP
 }
 
 // --------------------------------------------------------------------------- //
