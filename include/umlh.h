@@ -110,7 +110,21 @@ typedef struct {
 #define UMLH_S_GSCALE_TXT 5   /* d loss / d txt_scale                      */
 #define UMLH_S_CORRECT    6   /* eval: number of correct rows (as float)   */
 #define UMLH_S_LOSS_SUM   7   /* eval: sum of per-row CE                   */
-#define UMLH_N_SCALARS    8
+/* Per-step gradient diagnostics (finetune.py:190-191,203-206,238): raw sums over all C*d elements
+ * of the UNWEIGHTED per-modality head gradients g_img = dL_img/dW, g_txt = dL_txt/dW -- by-products
+ * of the split-K slab reduction (image and text rows occupy separate slabs).  Written by
+ * umlh_train_step(s) after umlh_enable_diagnostics(h, 1) (off by default: the accumulation costs
+ * about 2.5 us per step at C*d = 512 000) when d_shared % 8 == 0; left untouched by umlh_eval_batch, zero in the
+ * data-parallel split (umlh_grad_step / umlh_apply_update: per-modality gradients would need a
+ * second all-reduce) and for a modality whose loss weight is 0.  The caller forms
+ *   grad_direction_sim = DOT / sqrt(N2_IMG * N2_TXT),  img_grad_norm = sqrt(N2_IMG),
+ *   txt_grad_norm = sqrt(N2_TXT),  grad_agreement_rate = AGREE / (C * d). */
+#define UMLH_S_GRAD_DOT      8   /* sum g_img * g_txt                          */
+#define UMLH_S_GRAD_N2_IMG   9   /* sum g_img^2                                */
+#define UMLH_S_GRAD_N2_TXT   10  /* sum g_txt^2                                */
+#define UMLH_S_GRAD_AGREE    11  /* #elements with sign(g_img) == sign(g_txt)  */
+#define UMLH_N_CORE_SCALARS  8
+#define UMLH_N_SCALARS    12
 
 const char* umlh_last_error(void);
 int  umlh_version(void);
@@ -123,6 +137,10 @@ int  umlh_destroy(umlh_handle_t h);
 /* Attach parameter / optimizer-state / workspace buffers (state_dict round trips
  * stay on the torch side: finetune.py:249,274). */
 int  umlh_bind(umlh_handle_t h, const umlh_buffers_t* bufs);
+
+/* Per-step gradient diagnostics on/off (finetune.py:190-191,203-206: the reference computes them on
+ * every step with two extra backward passes; here they ride on the slab reduction).  Off by default. */
+int  umlh_enable_diagnostics(umlh_handle_t h, int32_t on);
 
 /* head.weight.data = get_zero_shot_weights(...)  head.py:22-37,96-98: per-class
  * mean of the text rows (rows of classes without text stay 0), rows L2-normalised. */

@@ -344,6 +344,15 @@ def train_run(tag, d_img, text_indim, C, n_img_per_class, n_txt, n_val, B, max_i
         val_calls.append((len(loader.dataset), r[0], r[1]))
         return r
     ref_finetune.validate = rec_validate
+    # the reference's per-modality head gradients (finetune.py:190-191): every torch.autograd.grad result
+    orig_grad = torch.autograd.grad
+    grad_calls = []
+
+    def rec_grad(outputs, inputs, *a, **k):
+        r = orig_grad(outputs, inputs, *a, **k)
+        grad_calls.append(r[0].detach().clone())
+        return r
+    torch.autograd.grad = rec_grad
     try:
         out = quiet(ref_finetune.train, model, image_loader, text_loader, val_loader, test_loader, optimizer,
                     scheduler, device="cpu", max_iters=max_iters, alpha=alpha, eval_freq=eval_freq,
@@ -351,13 +360,26 @@ def train_run(tag, d_img, text_indim, C, n_img_per_class, n_txt, n_val, B, max_i
     finally:
         F.cross_entropy = orig_ce
         ref_finetune.validate = orig_validate
+        torch.autograd.grad = orig_grad
     test_loss, test_acc = ref_finetune.validate(model, test_loader, device="cpu")   # finetune.py:390
     n_steps = len(img_log) and (len(train_ce) // (2 if modality == "crossmodal" else 1))
     vals = [(l, a) for (n, l, a) in val_calls if n == n_val]
+    # gradient diagnostics the reference logs per step, formed from ITS gradients with its own
+    # expressions (finetune.py:203-206,238); image-only runs log similarity 0 / agreement 0
+    diag = np.zeros((n_steps, 4), dtype=np.float64)      # sim, agreement, |g_img|, |g_txt|
+    per = 2 if modality == "crossmodal" else 1
+    for k in range(n_steps):
+        gi = torch.flatten(grad_calls[per * k])
+        gt = torch.flatten(grad_calls[per * k + 1]) if per == 2 else torch.zeros_like(gi)
+        if per == 2:
+            diag[k, 0] = float(torch.dot(gi, gt) / (torch.norm(gi) * torch.norm(gt)))
+            diag[k, 1] = float(torch.mean((torch.sign(gi) == torch.sign(gt)).float()))
+        diag[k, 2] = float(torch.norm(gi))
+        diag[k, 3] = float(torch.norm(gt))
     rec = dict(x_img=xi, y_img=yi, x_txt=xt, y_txt=yt, x_val=xv, y_val=yv, x_test=xe, y_test=ye,
                w_head_init=w_head_init, idx_img=np.asarray(img_log, dtype=np.int64),
                idx_txt=np.asarray(txt_log, dtype=np.int64),
-               train_ce=np.asarray(train_ce, dtype=np.float64), n_steps=n_steps,
+               train_ce=np.asarray(train_ce, dtype=np.float64), n_steps=n_steps, grad_diag=diag,
                val_loss=np.asarray([v[0] for v in vals]), val_acc=np.asarray([v[1] for v in vals]),
                best_iter=out["iter"], best_val_acc=out["val_acc"], best_val_loss=out["val_loss"],
                w_head_best=out["model"]["head.weight"], w_head_final=model.head.weight,

@@ -194,6 +194,21 @@ def step_grads(state: HeadState, x_img, y_img, x_txt, y_txt, alpha: float,
     return StepOut(li, lt, ai, at, grads, zi, zt, g_img, g_txt)
 
 
+def grad_diagnostics(g_img: Optional[np.ndarray], g_txt: Optional[np.ndarray]) -> Dict[str, float]:
+    """Per-step gradient diagnostics the reference logs (finetune.py:203-206,238) from the
+    UNWEIGHTED per-modality head gradients (finetune.py:190-191; an absent modality is
+    ``zeros_like`` there): cosine similarity and sign-agreement rate (both 0 unless both
+    modalities are present, :205-206) and the two Frobenius norms (:238)."""
+    both = g_img is not None and g_txt is not None
+    gi = None if g_img is None else g_img.ravel().astype(np.float64)
+    gt = None if g_txt is None else g_txt.ravel().astype(np.float64)
+    ni = 0.0 if gi is None else float(np.sqrt((gi * gi).sum()))
+    nt = 0.0 if gt is None else float(np.sqrt((gt * gt).sum()))
+    sim = float((gi * gt).sum() / (ni * nt)) if both else 0.0
+    agree = float((np.sign(g_img.ravel()) == np.sign(g_txt.ravel())).mean()) if both else 0.0
+    return {"grad_direction_sim": sim, "grad_agreement_rate": agree, "img_grad_norm": ni, "txt_grad_norm": nt}
+
+
 # --------------------------------------------------------------------------- #
 # optimizers (torch.optim semantics; built by engine/optimizer/optim.py:15-71)
 # --------------------------------------------------------------------------- #
@@ -496,6 +511,7 @@ def train_loop(state: HeadState, opt: OptState, sched: LRSchedule,
             record.setdefault("loss_img", []).append(so.loss_img)
             record.setdefault("loss_txt", []).append(so.loss_txt)
             record.setdefault("lr", []).append(lr)
+            record.setdefault("grad_diag", []).append(grad_diagnostics(so.g_head_img, so.g_head_txt))
             if img_batches is not None:
                 record.setdefault("idx_img", []).append(ii.copy())
             if txt_batches is not None:

@@ -13,7 +13,7 @@ class OracleEngine:
         self.opt = O.OptState(optimizer, wd)
         nh = state.w_head.size
         npj = state.w_proj.size if state.w_proj is not None else 0
-        self.flat = torch.zeros(nh + npj + 2 + 8, dtype=torch.float32)
+        self.flat = torch.zeros(nh + npj + 2 + 12, dtype=torch.float32)   # [.. | g_scales(2) | scalars(UMLH_N_SCALARS)]
         self.nh, self.npj = nh, npj
 
     @staticmethod

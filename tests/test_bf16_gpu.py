@@ -75,6 +75,30 @@ def test_bf16_grad_step_vs_oracle_on_rounded_operands(d, C, bi, bt, scale, stw, 
     assert np.abs(gh - ex.grads["w_head"]).max() < 5e-2 * np.abs(ex.grads["w_head"]).max()
 
 
+@pytest.mark.parametrize("d,C,bi,bt,alpha", [(512, 1000, 300, 257, 0.7), (128, 100, 70, 33, 1.0), (256, 37, 90, 0, 1.0)])
+def test_bf16_train_step_gradient_diagnostics(d, C, bi, bt, alpha):
+    """The per-modality gradient sums that ride on the slab reduction (finetune.py:190-191,203-206)
+    against the oracle's gradients on the same bf16-rounded operands."""
+    import umlh
+    rng = np.random.default_rng(7 * d + C)
+    xi, yi, xt, yt, w = _case(rng, d, C, 400, 350, 50.0)
+    ii = rng.permutation(400)[:bi]
+    ti = rng.permutation(350)[:bt] if bt else None
+    e = _engine(w, 50.0, 512, 512, "bf16")
+    e.enable_diagnostics()
+    sc = torch.zeros(umlh.N_SCALARS, device=DEV)
+    e.train_step(_rb(xi, yi, ii), _rb(xt, yt, ti) if bt else None, lr=1e-3, step=1, alpha=alpha, scalars_out=sc)
+    torch.cuda.synchronize()
+    got = umlh.grad_diagnostics(sc.cpu(), C * d, bi, bt)
+    st = O.HeadState(_bf16_round(w), None, 50.0, 50.0, False)
+    so = O.step_grads(st, _bf16_round(xi[ii]), yi[ii], _bf16_round(xt[ti]) if bt else None, yt[ti] if bt else None, alpha)
+    ref = O.grad_diagnostics(so.g_head_img, so.g_head_txt)
+    assert abs(got["grad_direction_sim"] - ref["grad_direction_sim"]) < 5e-3
+    assert abs(got["grad_agreement_rate"] - ref["grad_agreement_rate"]) < 2e-2
+    assert abs(got["img_grad_norm"] - ref["img_grad_norm"]) < 1e-2 * ref["img_grad_norm"]
+    assert abs(got["txt_grad_norm"] - ref["txt_grad_norm"]) <= 1e-2 * ref["txt_grad_norm"]
+
+
 def test_bf16_eval_batch():
     import umlh
     rng = np.random.default_rng(2)

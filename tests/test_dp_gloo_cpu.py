@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
         sel_i = np.arange(rank, len(yi), world)
         sel_t = np.arange(0, 13) if rank == 0 else np.arange(13, len(yt))
         T = torch.as_tensor
-        scal = torch.zeros(8)
+        scal = torch.zeros(12)
         for k in range(3):
             bi = umlh.RowBatch(T(xi), T(yi), T(sel_i), global_rows=len(yi))
             bt = umlh.RowBatch(T(xt), T(yt), T(sel_t), global_rows=len(yt))

@@ -44,7 +44,7 @@ def test_train_replays_reference_run(tag):
     val_loader = FeatureLoader(FeatureTable(T(g["x_val"]), T(g["y_val"]), DEV), B, shuffle=False)
     test_loader = FeatureLoader(FeatureTable(T(g["x_test"]), T(g["y_test"]), DEV), B, shuffle=False)
     out = ft.train(model, image_loader, text_loader, val_loader, test_loader, optimizer, scheduler, device=DEV,
-                   max_iters=max_iters, alpha=float(alpha), eval_freq=eval_freq, patience=patience)
+                   max_iters=max_iters, alpha=float(alpha), eval_freq=eval_freq, patience=patience, diagnostics=True)
     test_loss, test_acc = ft.validate(model, test_loader, device=DEV)
 
     n = int(g["n_steps"])
@@ -56,6 +56,15 @@ def test_train_replays_reference_run(tag):
     else:
         np.testing.assert_allclose(sc[:, umlh.S_LOSS_IMG], ce[0::2], atol=1e-4)
         np.testing.assert_allclose(sc[:, umlh.S_LOSS_TXT], ce[1::2], atol=1e-4)
+    # per-step gradient diagnostics (by-products of the slab reduction) vs the reference's own gradients
+    gd = g["grad_diag"]
+    n_el = model.head.weight.numel()
+    has_txt = modality != "image"
+    dg = [umlh.grad_diagnostics(row, n_el, 1, 1 if has_txt else 0) for row in out["train_scalars"]]
+    got = np.asarray([[r["grad_direction_sim"], r["grad_agreement_rate"], r["img_grad_norm"], r["txt_grad_norm"]] for r in dg])
+    np.testing.assert_allclose(got[:, 0], gd[:, 0], atol=5e-4)
+    np.testing.assert_allclose(got[:, 1], gd[:, 1], atol=5e-3)
+    np.testing.assert_allclose(got[:, 2:], gd[:, 2:], rtol=2e-3, atol=1e-7)
     assert out["iter"] == int(g["best_iter"])
     assert abs(out["val_acc"] - float(g["best_val_acc"])) < 1e-6
     assert abs(out["val_loss"] - float(g["best_val_loss"])) < 1e-4

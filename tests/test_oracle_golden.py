@@ -166,6 +166,13 @@ def test_full_train_run_matches_reference(tag):
         np.testing.assert_array_equal(np.concatenate(rec["idx_txt"]), g["idx_txt"])
         np.testing.assert_allclose(rec["loss_img"], ce[0::2], atol=1e-4)
         np.testing.assert_allclose(rec["loss_txt"], ce[1::2], atol=1e-4)
+    # per-step gradient diagnostics formed from the reference's own torch.autograd.grad results
+    gd = g["grad_diag"]
+    od = np.asarray([[r["grad_direction_sim"], r["grad_agreement_rate"], r["img_grad_norm"], r["txt_grad_norm"]]
+                     for r in rec["grad_diag"]])
+    np.testing.assert_allclose(od[:, 0], gd[:, 0], atol=2e-4)
+    np.testing.assert_allclose(od[:, 1], gd[:, 1], atol=2e-3)       # sign flips of elements at rounding level
+    np.testing.assert_allclose(od[:, 2:], gd[:, 2:], rtol=1e-3, atol=1e-7)
     # reference validates once more after restoring the best weights (finetune.py:275)
     np.testing.assert_allclose(rec["val_acc"], g["val_acc"][:len(rec["val_acc"])], atol=1e-6)
     np.testing.assert_allclose(rec["val_loss"], g["val_loss"][:len(rec["val_loss"])], atol=1e-4)

@@ -19,7 +19,8 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
                               float* grad_out, float* p, float* m, float* v, const OptArgs* o, hipStream_t stream);
 int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream);
 int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
-                          float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out, hipStream_t stream);
+                          float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out,
+                          const DiagArgs* dg, hipStream_t stream);
 int umlh_launch_zero_shot(const float* feats, const int64_t* labels, long long n, int d, int C, float* w,
                           hipStream_t stream);
 int umlh_launch_to_bf16(const float* src, void* dst, long long n, hipStream_t stream);
@@ -56,9 +57,32 @@ struct Layout {                 // workspace partition, in floats from the base
 static int split_cap(int M, int N) {
     long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
     long long want = 256 / tiles;
-    if (want < 1) want = 1;
+    if (want < 2) want = 2;           // image rows and text rows never share a slab (plan_splits)
     if (want > 64) want = 64;
     return (int)want;
+}
+
+// Modality-aligned split-K plan for dW_head: `r0` reduction rows of the image segment followed by `r1`
+// of the text segment, at most `want` slabs of `chunk` rows (a multiple of `quantum`) each, every slab
+// inside one modality.  Keeping the two partial sums in separate slabs makes the reference's
+// per-modality gradients (finetune.py:190-191) by-products of the slab reduction.
+struct SplitPlan { int chunk, n_img, n_txt; };
+static SplitPlan plan_splits(int r0, int r1, int want, int quantum, int min_chunk) {
+    SplitPlan sp = {min_chunk, 0, 0};
+    const long long tot = (long long)r0 + r1;
+    if (tot <= 0) return sp;
+    int s0 = r0 > 0 ? (int)((want * (long long)r0 + tot / 2) / tot) : 0;
+    if (r0 > 0 && s0 < 1) s0 = 1;
+    if (r1 > 0 && s0 > want - 1) s0 = want - 1;
+    int s1 = r1 > 0 ? want - s0 : 0;
+    if (r1 > 0 && s1 < 1) s1 = 1;
+    long long c0 = s0 > 0 ? (r0 + s0 - 1) / s0 : 0, c1 = s1 > 0 ? (r1 + s1 - 1) / s1 : 0;
+    long long chunk = round_up(c0 > c1 ? c0 : c1, quantum);
+    if (chunk < min_chunk) chunk = min_chunk;
+    sp.chunk = (int)chunk;
+    sp.n_img = (int)((r0 + chunk - 1) / chunk);
+    sp.n_txt = (int)((r1 + chunk - 1) / chunk);
+    return sp;
 }
 
 static bool make_layout(const umlh_config_t& c, Layout& L) {
@@ -75,7 +99,7 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     L.n_head = (long long)c.num_classes * c.d_shared;
     L.n_proj = c.has_proj ? (long long)c.d_shared * c.d_img : 0;
     L.scap_head = split_cap(c.num_classes, c.d_shared);
-    if (c.precision == UMLH_PREC_BF16 && L.scap_head < (L.ldz + 4095) / 4096) L.scap_head = (L.ldz + 4095) / 4096;
+    if (c.precision == UMLH_PREC_BF16 && L.scap_head < (L.ldz + 4095) / 4096 + 1) L.scap_head = (L.ldz + 4095) / 4096 + 1;
     L.scap_proj = c.has_proj ? split_cap(c.d_shared, c.d_img) : 0;
     L.max_blocks = L.ldz / 32 + 2;
     long long off = 0;
@@ -108,6 +132,9 @@ struct umlh_handle_s {
     int last_rows_img, last_rows_txt;
     bool iota_ready;            // bf16: identity row-id table in the workspace initialised
     bool shadow_fresh;          // bf16: the W shadow was written by the previous step's update kernel
+    float* diag_dst;            // this step's 4 gradient-diagnostic accumulators (zeroed by the forward kernel)
+    int n_slabs_img;            // dW_head slabs that hold image rows (the rest hold text rows)
+    bool diagnostics;           // umlh_enable_diagnostics
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
     bool profiling;
 };
@@ -117,7 +144,13 @@ static inline void mark(umlh_handle_t h, int i, hipStream_t st) {
 }
 
 const char* umlh_last_error(void) { return g_err; }
-int umlh_version(void) { return 1; }
+int umlh_version(void) { return 2; }
+
+int umlh_enable_diagnostics(umlh_handle_t h, int32_t on) {
+    if (!h) return fail(UMLH_E_INVALID, "umlh_enable_diagnostics: null handle");
+    h->diagnostics = on != 0;
+    return UMLH_OK;
+}
 
 uint64_t umlh_workspace_bytes(const umlh_config_t* cfg) {
     Layout L;
@@ -425,18 +458,19 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         fb.partials = ws(h, L.partials);
         { const char* e = getenv("UMLH_DBG_FWD"); fb.dbg = e ? atoi(e) : 0; }
         fb.learn = c.learnable_temp;
+        fb.diag_zero = h->diag_dst;
         fb.stamps = fb.dbg == 9 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
         mark(h, 2, st);
         *n_slabs_head = 0; *n_slabs_proj = 0;
         if (!want_grad) return UMLH_OK;
         const int rcols_b = r0p + r1p;
-        int want = L.scap_head;
-        int chunk = (int)round_up((rcols_b + want - 1) / want, 256);      // 4-stage pipeline: multiples of 4 x 64 columns
-        if (chunk > 4096) chunk = 4096;                                    // row ids of a split live in LDS
-        if ((rcols_b + chunk - 1) / chunk > L.scap_head)
-            return fail(UMLH_E_INVALID, "bf16 dW: %d reduction rows need more than %d split-K slabs", rcols_b, L.scap_head);
-        int splits = (rcols_b + chunk - 1) / chunk;
+        // chunk: multiples of 4 x 64 columns (4-stage pipeline), at most 4096 (row ids of a split live in LDS)
+        SplitPlan sp = plan_splits(r0p, r1p, L.scap_head, 256, 256);
+        if (sp.chunk > 4096) { sp.chunk = 4096; sp.n_img = (r0p + 4095) / 4096; sp.n_txt = (r1p + 4095) / 4096; }
+        const int chunk = sp.chunk, splits = sp.n_img + sp.n_txt;
+        if (splits > L.scap_head)
+            return fail(UMLH_E_INVALID, "bf16 dW: %d + %d reduction rows need more than %d split-K slabs", r0p, r1p, L.scap_head);
         // the dW loader is branch-free: every pointer must be dereferenceable, also for an absent
         // modality or a dense (index-less) batch -> identity row ids from the workspace
         int64_t* iota = reinterpret_cast<int64_t*>(ws(h, L.iota));
@@ -457,7 +491,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         g.out = ws(h, L.slabs_head); g.ldo = c.d_shared;
         g.M = c.num_classes; g.N = c.d_shared; g.K = rcols_b;
         g.k_chunk = chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
-        g.nsplit = splits;
+        g.nsplit = splits; g.nsplit1 = sp.n_img; h->n_slabs_img = sp.n_img;
         { const char* e = getenv("UMLH_DBG_DW"); g.dbg = e ? atoi(e) : 0; }
         if (g.dbg >= 16) { g.dbg -= 16; g.stamps = reinterpret_cast<unsigned long long*>(ws(h, L.dbg)); }   // +16: cycle stamps
         HIPCHK(umlh_bf16_launch_dw(&g, splits, st), "dw_bf16");
@@ -493,6 +527,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     fa.W = h->buf.w_head; fa.C = c.num_classes; fa.K = c.d_shared;
     fa.dzt = want_grad ? dzt : nullptr; fa.ldz = L.ldz;
     fa.partials = ws(h, L.partials);
+    fa.diag_zero = h->diag_dst;
     HIPCHK(umlh_f32_launch_fwd(&fa, h->ctw, h->wc, nb0 + nb1, st), "fwd_ce");
     mark(h, 2, st);
     if (!want_grad) return UMLH_OK;
@@ -500,10 +535,10 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     // dW_head[c][k] = sum_r dZ^T[c][r] F[r][k]  over image rows then text rows
     const int rcols = r0p + r1p;
     {
-        int want = L.scap_head;
-        int chunk = (int)round_up((rcols + want - 1) / want, KT);
-        if (chunk < 64) chunk = 64;
-        int splits = (rcols + chunk - 1) / chunk;
+        const SplitPlan sp = plan_splits(r0p, r1p, L.scap_head, KT, 64);
+        const int chunk = sp.chunk, splits = sp.n_img + sp.n_txt;
+        if (splits > L.scap_head)
+            return fail(UMLH_E_INVALID, "dW: %d + %d reduction rows need more than %d split-K slabs", r0p, r1p, L.scap_head);
         GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.A = dzt; g.lda = L.ldz;
@@ -514,7 +549,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         g.B2 = txt ? txt->feats : nullptr; g.k_rows2 = txt ? txt->index : nullptr; g.ldb2 = c.d_shared;
         g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt;
         g.out = ws(h, L.slabs_head); g.ldo = c.d_shared;
-        g.k_chunk = chunk; g.slab_stride = L.n_head; g.alpha = 1.f;
+        g.k_chunk = chunk; g.slab_stride = L.n_head; g.alpha = 1.f; g.nsplit1 = sp.n_img; h->n_slabs_img = sp.n_img;
         HIPCHK(umlh_f32_launch_gemm(&g, 0, 1, splits, st), "dW_head gemm");
         *n_slabs_head = splits;
     }
@@ -589,17 +624,25 @@ static int check_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch
 static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
                            float* scalars_out, hipStream_t st, bool keep_shadow) {
     int sh = 0, sp = 0;
+    // gradient diagnostics: accumulators in the caller's scalar row (or the workspace tail), zeroed by the
+    // forward kernel, added to by the head-step blocks
+    float* tail = ws(h, h->L.grads) + h->L.n_head + h->L.n_proj;
+    h->diag_dst = h->diagnostics ? (scalars_out ? scalars_out : tail + 2) + UMLH_N_CORE_SCALARS : nullptr;
     int rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
     if (rc) return rc;
     OptArgs o = make_opt(h->cfg, *hy);
     FinalizeArgs f = make_finalize(h, img, txt, hy, true, scalars_out, true);
     const umlh_config_t& c = h->cfg;
+    DiagArgs dg;
+    dg.dst = h->diag_dst; dg.n_slabs_img = h->n_slabs_img;
+    dg.inv_w0 = hy->img_alpha != 0.f ? 1.f / hy->img_alpha : 0.f;
+    dg.inv_w1 = hy->alpha != 0.f ? 1.f / hy->alpha : 0.f;
     if (c.d_shared % 8 == 0) {
         // one launch: slab sum + optimizer + (bf16) next step's W shadow + scalars / logit scales
         const bool bf = c.precision == UMLH_PREC_BF16;
         HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, h->L.n_head, c.num_classes, c.d_shared, h->buf.w_head,
                                      h->buf.m_head, h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr,
-                                     32 * h->ctw * h->wc, &f, nullptr, st), "head step");
+                                     32 * h->ctw * h->wc, &f, nullptr, &dg, st), "head step");
         h->shadow_fresh = bf && keep_shadow;
     } else {
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
@@ -663,6 +706,9 @@ int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t*
     hipStream_t st = (hipStream_t)stream;
     int sh = 0, sp = 0;
     if (!(hy->flags & UMLH_F_WEIGHTS_UNCHANGED)) h->shadow_fresh = false;
+    // the diagnostic slots of the flat buffer are zeroed (per-modality gradients of a data-parallel step
+    // would need a second all-reduce; not produced)
+    h->diag_dst = ws(h, h->L.grads) + h->L.n_head + h->L.n_proj + 2 + UMLH_N_CORE_SCALARS;
     rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
     if (rc) return rc;
     OptArgs o = make_opt(h->cfg, *hy);
@@ -670,7 +716,7 @@ int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t*
     float* grads = ws(h, h->L.grads);
     if (h->cfg.d_shared % 8 == 0) {
         HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, h->L.n_head, h->cfg.num_classes, h->cfg.d_shared, nullptr,
-                                     nullptr, nullptr, &o, nullptr, 32 * h->ctw * h->wc, &f, grads, st), "reduce head");
+                                     nullptr, nullptr, &o, nullptr, 32 * h->ctw * h->wc, &f, grads, nullptr, st), "reduce head");
     } else {
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
         HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, grads, nullptr,
@@ -714,7 +760,7 @@ int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_ou
         const bool bf = h->cfg.precision == UMLH_PREC_BF16;
         HIPCHK(umlh_launch_head_step(grads, 1, h->L.n_head, h->cfg.num_classes, h->cfg.d_shared, h->buf.w_head, h->buf.m_head,
                                      h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr, 32 * h->ctw * h->wc, &f, nullptr,
-                                     st), "update head");
+                                     nullptr, st), "update head");
         h->shadow_fresh = bf;              // the next umlh_grad_step may trust it (see umlh_grad_step)
     } else {
         HIPCHK(umlh_launch_reduce_update(1, grads, 1, h->L.n_head, h->L.n_head, nullptr, h->buf.w_head, h->buf.m_head,
@@ -739,6 +785,7 @@ int umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* b, float* scalars_out, 
     hy.lr = 0; hy.step = 1; hy.alpha = 1.f; hy.img_alpha = 1.f;
     int sh = 0, sp = 0;
     h->shadow_fresh = false;
+    h->diag_dst = nullptr;
     rc = forward_backward(h, b, nullptr, &hy, false, st, &sh, &sp);
     if (rc) return rc;
     FinalizeArgs f = make_finalize(h, b, nullptr, &hy, true, scalars_out, false);

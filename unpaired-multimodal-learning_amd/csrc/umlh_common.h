@@ -35,6 +35,7 @@ struct FwdArgs {
     float* dzt;                  // [C, ldz] dZ^T (class-major), NULL = eval (no gradient)
     int   ldz;
     float* partials;             // [grid][4] = {loss_sum, correct, gscale_sum, 0}
+    float* diag_zero;            // 4 floats zeroed by block 0 (gradient-diagnostic accumulators of this step), or NULL
 };
 
 // ---- generic fp32 GEMM: out[m][n] = alpha * sum_k A(m,k) * B(n,k) ----
@@ -55,6 +56,9 @@ struct GemmArgs {
     int   ldb2;
     int   k_switch;
     int   k_valid1, k_valid2;
+    // > 0: modality-aligned split-K -- slabs [0, nsplit1) cover k in [0, k_switch) and the rest cover
+    // [k_switch, K), k_chunk rows each (image and text gradients stay in separate slabs); 0: uniform
+    int   nsplit1;
 };
 
 // ---- bf16-mode argument blocks (kernels in umlh_kernels_bf16.hip, filled by umlh_api.cpp) ----
@@ -79,6 +83,7 @@ struct FwdArgsB {
     int   dbg;                   // timing-only ablations: 1 = main loop only, 2 = epilogue only
     int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
     unsigned long long* stamps;  // diagnostic build only (UMLH_DBG_FWD=9): [grid][8] s_memtime stamps of wave 0
+    float* diag_zero;            // 4 floats zeroed by block 0 (gradient-diagnostic accumulators of this step), or NULL
 };
 
 struct DwArgsB {
@@ -89,6 +94,7 @@ struct DwArgsB {
     const u16* zeros;            // >= 16 B of zeros (source of masked loads)
     int   dbg;                   // timing-only ablations: bit0 = no A traffic, bit1 = no F traffic
     int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit;
+    int   nsplit1;               // slabs [0, nsplit1) cover k in [0, k_switch), the rest [k_switch, K): k_chunk rows each
     long long slab_stride;
     unsigned long long* stamps;  // diagnostics (UMLH_DBG_DW=16+bits): [blocks][8 waves][8] cycle stamps, else NULL
 };
@@ -111,6 +117,13 @@ struct FinalizeArgs {
     float* scales; float* m_scales; float* v_scales;   // [2]
     int   update_mask;           // bit0: update img_scale, bit1: txt_scale
     OptArgs opt;
+};
+
+// gradient diagnostics of one step, by-products of the slab reduction (head_step_kernel)
+struct DiagArgs {
+    float* dst;                  // 4 accumulators {dot, |g_img|^2, |g_txt|^2, sign agreements}, zeroed by the forward; NULL = off
+    int   n_slabs_img;           // slabs [0, n_slabs_img) hold the image rows' partial sums
+    float inv_w0, inv_w1;        // 1 / loss weight of each modality (0 if the weight is 0)
 };
 
 // torch.optim single-tensor update of one element (see oracle/uml_oracle.py

@@ -449,6 +449,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 #pragma unroll
         for (int w = 0; w < WS; ++w) { l += red2[w * 4 + 0]; c += red2[w * 4 + 1]; g += red2[w * 4 + 2]; }
         float* o = a.partials + (size_t)blockIdx.x * 4;
+        if (blockIdx.x == 0 && a.diag_zero != nullptr) { a.diag_zero[0] = a.diag_zero[1] = a.diag_zero[2] = a.diag_zero[3] = 0.f; }
         o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
     }
     STAMP(5);
@@ -489,8 +490,10 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     const int bid = blockIdx.x;
     const int z = bid % g.nsplit, t = bid / g.nsplit;
     const int m0 = (t / nx) * DBM, n0 = (t % nx) * DBN;
-    const int kb = z * g.k_chunk;                       // multiple of DKT
-    const int ke = min(g.K, kb + g.k_chunk);
+    // modality-aligned split-K: slabs [0, nsplit1) cover the image rows [0, k_switch), the rest the text
+    // rows [k_switch, K) -- their sums stay separable (per-modality gradient diagnostics)
+    const int kb = z < g.nsplit1 ? z * g.k_chunk : g.k_switch + (z - g.nsplit1) * g.k_chunk;    // multiple of DKT
+    const int ke = min(z < g.nsplit1 ? g.k_switch : g.K, kb + g.k_chunk);
     const int nchunks = g.k_chunk / DKT;                // multiple of DNS
 
     f32x16 acc[2];

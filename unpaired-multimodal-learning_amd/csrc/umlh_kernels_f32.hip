@@ -277,6 +277,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
 #pragma unroll
         for (int w = 0; w < WS; ++w) { l += red2[w * 4 + 0]; c += red2[w * 4 + 1]; g += red2[w * 4 + 2]; }
         float* o = a.partials + (size_t)blockIdx.x * 4;
+        if (blockIdx.x == 0 && a.diag_zero != nullptr) { a.diag_zero[0] = a.diag_zero[1] = a.diag_zero[2] = a.diag_zero[3] = 0.f; }
         o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
     }
 }
@@ -300,8 +301,12 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-    const int kb = blockIdx.z * g.k_chunk;
-    const int ke = min(g.K, kb + g.k_chunk);
+    int kb = blockIdx.z * g.k_chunk, ke = min(g.K, kb + g.k_chunk);
+    if (g.nsplit1 > 0) {                                  // modality-aligned split-K
+        const int z = blockIdx.z;
+        if (z < g.nsplit1) ke = min(g.k_switch, kb + g.k_chunk);
+        else { kb = g.k_switch + (z - g.nsplit1) * g.k_chunk; ke = min(g.K, kb + g.k_chunk); }
+    }
 
     auto kvalid = [&](int k) -> bool {
         return k < g.k_switch ? (k < g.k_valid1) : (k - g.k_switch < g.k_valid2);
@@ -559,7 +564,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& f, float (*sh)
         }
         __syncthreads();
     }
-    if (tid < UMLH_N_SCALARS && f.scalars_out) f.scalars_out[tid] = f.tail[2 + tid];
+    if (tid < UMLH_N_CORE_SCALARS && f.scalars_out) f.scalars_out[tid] = f.tail[2 + tid];
     if (tid < 2 && ((f.update_mask >> tid) & 1)) {
         float p = f.scales[tid], m = f.m_scales[tid], v = f.v_scales[tid];
         opt_update(f.opt, f.tail[tid], p, m, v);
@@ -588,19 +593,57 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                         int C, int K, float* __restrict__ p, float* __restrict__ m,
                                                         float* __restrict__ v, OptArgs o, unsigned short* __restrict__ shadow,
-                                                        int cpad, FinalizeArgs f, float* __restrict__ grad_out) {
+                                                        int cpad, FinalizeArgs f, float* __restrict__ grad_out, DiagArgs dg) {
     __shared__ float sh[6][256];
     if (blockIdx.x == gridDim.x - 1) { finalize_body(f, sh); return; }
     const long long g8 = (long long)blockIdx.x * 256 + threadIdx.x;      // group of 8 consecutive k of one class row
     const long long n8 = (long long)C * K / 8;
-    if (g8 >= n8) return;
-    const long long i = g8 * 8;
-    f32x4v g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < n_slabs; ++s) {
-        const float* q = slabs + (size_t)s * slab_stride + i;
-        g0 += *reinterpret_cast<const f32x4v*>(q);
-        g1 += *reinterpret_cast<const f32x4v*>(q + 4);
+    const bool live = g8 < n8;
+    const long long i = (live ? g8 : 0) * 8;
+    // image slabs and text slabs are summed separately (the split-K is modality-aligned): their
+    // dot product / norms / sign agreement are the reference's per-step gradient diagnostics
+    f32x4v gi0 = {0.f, 0.f, 0.f, 0.f}, gi1 = gi0, gt0 = gi0, gt1 = gi0;
+    if (live) {
+        for (int s = 0; s < dg.n_slabs_img; ++s) {
+            const float* q = slabs + (size_t)s * slab_stride + i;
+            gi0 += *reinterpret_cast<const f32x4v*>(q);
+            gi1 += *reinterpret_cast<const f32x4v*>(q + 4);
+        }
+        for (int s = dg.n_slabs_img; s < n_slabs; ++s) {
+            const float* q = slabs + (size_t)s * slab_stride + i;
+            gt0 += *reinterpret_cast<const f32x4v*>(q);
+            gt1 += *reinterpret_cast<const f32x4v*>(q + 4);
+        }
     }
+    if (dg.dst != nullptr) {                                 // uniform over the grid
+        float dot = 0.f, n2i = 0.f, n2t = 0.f, agree = 0.f;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = (j < 4 ? gi0[j & 3] : gi1[j & 3]) * dg.inv_w0;
+                const float b = (j < 4 ? gt0[j & 3] : gt1[j & 3]) * dg.inv_w1;
+                dot = __builtin_fmaf(a, b, dot);
+                n2i = __builtin_fmaf(a, a, n2i);
+                n2t = __builtin_fmaf(b, b, n2t);
+                const int sa = (a > 0.f) - (a < 0.f), sb = (b > 0.f) - (b < 0.f);
+                agree += sa == sb ? 1.f : 0.f;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dot += __shfl_xor(dot, off); n2i += __shfl_xor(n2i, off);
+            n2t += __shfl_xor(n2t, off); agree += __shfl_xor(agree, off);
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[0][w] = dot; sh[1][w] = n2i; sh[2][w] = n2t; sh[3][w] = agree; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const float t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+            __hip_atomic_fetch_add(dg.dst + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!live) return;
+    const f32x4v g0 = gi0 + gt0, g1 = gi1 + gt1;
     if (grad_out != nullptr) {             // data-parallel split: gradient only, the update follows the all-reduce
         *reinterpret_cast<f32x4v*>(grad_out + i) = g0;
         *reinterpret_cast<f32x4v*>(grad_out + i + 4) = g1;
@@ -774,11 +817,14 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
 
 int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
                           float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out,
-                          hipStream_t stream) {
+                          const DiagArgs* dg, hipStream_t stream) {
     long long n8 = (long long)C * K / 8;
     int blocks = (int)((n8 + 255) / 256) + 1;                 // + the finalize block
+    DiagArgs d;
+    if (dg) d = *dg; else { d.dst = nullptr; d.n_slabs_img = n_slabs; d.inv_w0 = d.inv_w1 = 0.f; }
+    if (d.n_slabs_img > n_slabs) d.n_slabs_img = n_slabs;
     hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, *o,
-                       (unsigned short*)shadow, cpad, *f, grad_out);
+                       (unsigned short*)shadow, cpad, *f, grad_out, d);
     return (int)hipGetLastError();
 }
 

@@ -91,7 +91,7 @@ def _state_dict_cpu(model):
 
 def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, scheduler, device="cuda",
           max_iters=1000, alpha=1.0, eval_freq=EVAL_FREQ, patience=5, capture_features_during_training=False,
-          features_pth="./", args=None, logger=None, precision="fp32"):
+          features_pth="./", args=None, logger=None, precision="fp32", diagnostics=None):
     out = {"iter": None, "val_acc": None, "model": None, "val_classwise": None, "val_loss": None,
            "model_records": []}
     model.train()
@@ -103,6 +103,9 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
     txt_src = _RowSource(text_loader, dev, "text", precision) if text_loader is not None else None
     engine = model.fused_engine(optimizer, max_rows_img=img_src.capacity if img_src else 32,
                                 max_rows_txt=txt_src.capacity if txt_src else 32, precision=precision)
+    # per-step gradient diagnostics (finetune.py:190-191,203-206): the reference computes them on every
+    # step; here they cost ~2.5 us per step, so they are on when a logger asks for them (or on request)
+    engine.enable_diagnostics(bool(diagnostics) if diagnostics is not None else logger is not None)
     scalars = torch.zeros(max_iters, umlh.N_SCALARS, dtype=torch.float32, device=dev)
     no_improve = 0
     img_alpha = 1.0
@@ -140,9 +143,14 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
         last_i = i
         if logger is not None:
             s = scalars[i].cpu()                      # host sync: only when a logger asks for per-step values
+            # finetune.py:236-240 (the CKA / mutual-kNN / in-class-distance entries belong to the
+            # feature-capture mode, which is outside this path)
+            gd = umlh.grad_diagnostics(s, model.head.weight.numel(), 0 if img_src is None else 1, 0 if txt_src is None else 1)
             logger.log({"train/image_loss": float(s[umlh.S_LOSS_IMG]), "train/text_loss": float(s[umlh.S_LOSS_TXT]),
                         "train/image_acc": float(s[umlh.S_ACC_IMG]), "train/text_acc": float(s[umlh.S_ACC_TXT]),
-                        "train/lr": scheduler.get_last_lr()[0]})
+                        "train/lr": scheduler.get_last_lr()[0],
+                        "train/grad_direction_sim": gd["grad_direction_sim"], "train/img_grad_norm": gd["img_grad_norm"],
+                        "train/txt_grad_norm": gd["txt_grad_norm"], "train/grad_agreement_rate": gd["grad_agreement_rate"]})
         if i % eval_freq == 0:
             state_dict_cpu = _state_dict_cpu(model)
             val_loss, val_acc = validate(model, val_loader, device=device)

@@ -7,6 +7,6 @@ creating a handle fails loudly without a GPU.
 """
 from ._lib import (UmlhError, build_library, lib_path, load_library, OPT_IDS, PREC_IDS,  # noqa: F401
                    N_SCALARS, S_LOSS_IMG, S_LOSS_TXT, S_ACC_IMG, S_ACC_TXT, S_GSCALE_IMG, S_GSCALE_TXT,
-                   S_CORRECT, S_LOSS_SUM)
-from .head_engine import HeadEngine, RowBatch, optimizer_step, random_permutation, to_bf16  # noqa: F401
+                   S_CORRECT, S_LOSS_SUM, S_GRAD_DOT, S_GRAD_N2_IMG, S_GRAD_N2_TXT, S_GRAD_AGREE, N_CORE_SCALARS)
+from .head_engine import HeadEngine, RowBatch, grad_diagnostics, optimizer_step, random_permutation, to_bf16  # noqa: F401
 from .dp import DataParallelStepper  # noqa: F401,E402

@@ -15,11 +15,13 @@ _SO = os.path.join(_HERE, "libumlh.so")
 
 OPT_IDS = {"sgd": 0, "adam": 1, "adamw": 2}          # engine/optimizer/optim.py:6 AVAI_OPTIMS
 PREC_IDS = {"fp32": 0, "bf16": 1}
-(S_LOSS_IMG, S_LOSS_TXT, S_ACC_IMG, S_ACC_TXT, S_GSCALE_IMG, S_GSCALE_TXT, S_CORRECT, S_LOSS_SUM) = range(8)
-N_SCALARS = 8
+(S_LOSS_IMG, S_LOSS_TXT, S_ACC_IMG, S_ACC_TXT, S_GSCALE_IMG, S_GSCALE_TXT, S_CORRECT, S_LOSS_SUM,
+ S_GRAD_DOT, S_GRAD_N2_IMG, S_GRAD_N2_TXT, S_GRAD_AGREE) = range(12)
+N_CORE_SCALARS = 8
+N_SCALARS = 12
 
 SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_seq.hip", "umlh_api.cpp"]
-EXPORTS = ["umlh_last_error", "umlh_version", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
+EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
@@ -105,6 +107,7 @@ def load_library():
     lib.umlh_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.umlh_destroy.argtypes = [vp]
     lib.umlh_bind.argtypes = [vp, C.POINTER(Buffers)]
+    lib.umlh_enable_diagnostics.argtypes = [vp, C.c_int32]
     lib.umlh_zero_shot_init.argtypes = [vp, vp, vp, i64, vp]
     lib.umlh_logits.argtypes = [vp, C.POINTER(Batch), C.c_int, vp, vp]
     lib.umlh_train_step.argtypes = [vp, C.POINTER(Batch), C.POINTER(Batch), C.POINTER(Hyper), vp, vp]

@@ -168,6 +168,10 @@ class HeadEngine:
             check(self.lib.umlh_project(self.handle, C.byref(b), _ptr(out), self._stream()), "umlh_project")
         return out
 
+    def enable_diagnostics(self, on: bool = True) -> None:
+        """Per-step gradient diagnostics (S_GRAD_* scalars; see ``grad_diagnostics``) on/off."""
+        check(self.lib.umlh_enable_diagnostics(self.handle, 1 if on else 0), "umlh_enable_diagnostics")
+
     def train_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], lr: float, step: int,
                    alpha: float = 1.0, img_alpha: float = 1.0, scalars_out: Optional[torch.Tensor] = None):
         bi, bt = self._batch(img, self.d_img), self._batch(txt, self.d_shared)
@@ -282,6 +286,25 @@ class HeadEngine:
         so = scalars_out if scalars_out is not None else self._scalars
         check(self.lib.umlh_eval_batch(self.handle, self._ref(b), _ptr(so), self._stream()), "umlh_eval_batch")
         return so
+
+
+def grad_diagnostics(scalars, n_elements: int, rows_img: int = 1, rows_txt: int = 1) -> dict:
+    """The reference's per-step gradient diagnostics (finetune.py:203-206,238) from one scalar row
+    written by ``train_step`` / ``train_steps``: the kernels accumulate the raw sums
+    (S_GRAD_DOT, S_GRAD_N2_IMG, S_GRAD_N2_TXT, S_GRAD_AGREE); the ratios are formed here, at logging
+    time.  ``n_elements`` = C * d of the head weight.  With a modality absent the reference logs
+    similarity 0 and agreement 0 (finetune.py:205-206)."""
+    import math
+    row = [float(x) for x in scalars[:_lib.N_SCALARS].tolist()]
+    n2i, n2t = row[_lib.S_GRAD_N2_IMG], row[_lib.S_GRAD_N2_TXT]
+    both = rows_img > 0 and rows_txt > 0
+    den = math.sqrt(n2i) * math.sqrt(n2t)
+    return {
+        "grad_direction_sim": (row[_lib.S_GRAD_DOT] / den if den > 0 else float("nan")) if both else 0.0,
+        "img_grad_norm": math.sqrt(n2i),
+        "txt_grad_norm": math.sqrt(n2t),
+        "grad_agreement_rate": row[_lib.S_GRAD_AGREE] / float(n_elements) if both else 0.0,
+    }
 
 
 def optimizer_step(name: str, param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: Optional[torch.Tensor], *,
