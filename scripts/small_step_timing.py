@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Wall time of cfg1-shaped (batch 32+32, C=100, d=512) fused steps, enqueued 100 at a time."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "unpaired-multimodal-learning_amd"))
+import torch
+import umlh
+DEV = "cuda:0"
+C, d, B = 100, 512, int(sys.argv[1]) if len(sys.argv) > 1 else 32
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+g = torch.Generator(device=DEV).manual_seed(0)
+x = torch.nn.functional.normalize(torch.randn(4096, d, generator=g, device=DEV), dim=1)
+y = torch.randint(0, C, (4096,), generator=g, device=DEV)
+x16 = umlh.to_bf16(x)
+e = umlh.HeadEngine(d, d, C, optimizer="adamw", weight_decay=0.01, max_rows_img=B, max_rows_txt=B, precision=prec, device=DEV)
+e.w_head.normal_(0, 0.05); e.scales.fill_(100.0)
+n = 100
+tab = (x, y, x16) if prec == "bf16" else (x, y)
+for rep in range(4):
+    bi = [torch.randint(0, 4096, (B,), generator=g, device=DEV) for _ in range(n)]
+    bt = [torch.randint(0, 4096, (B,), generator=g, device=DEV) for _ in range(n)]
+    sc = torch.zeros(n, umlh.N_SCALARS, device=DEV)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e.train_steps(tab, bi, tab, bt, [1e-3] * n, first_step=1 + rep * n, scalars_out=sc)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    w = e.w_head.detach().cpu().clone()
+    t3 = time.perf_counter()
+    print(f"rep {rep}: enqueue {1e6 * (t1 - t0) / n:7.1f} us/step   drain {1e6 * (t2 - t1) / n:7.1f} us/step   total {1e6 * (t2 - t0) / n:7.1f} us/step   state copy {1e3 * (t3 - t2):.2f} ms")

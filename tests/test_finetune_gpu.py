@@ -114,3 +114,56 @@ def test_model_forward_and_optimizer_step_unfused():
     z, _ = c(x)
     ref = (x.cpu().numpy() @ c.head.weight.detach().cpu().numpy().T) * np.float32(np.exp(np.log(1 / 0.07)))
     np.testing.assert_allclose(z.cpu().numpy(), ref, atol=1e-4)
+
+
+def _toy_dataset(seed=5, C=12, d=64, n_per=10, n_txt=80, n_val=60):
+    g = torch.Generator().manual_seed(seed)
+    proto = torch.randn(C, d, generator=g)
+
+    def draw(n):
+        y = torch.randint(0, C, (n,), generator=g)
+        x = torch.nn.functional.normalize(proto[y] + 1.5 * torch.randn(n, d, generator=g), dim=1)
+        return x, y
+    xi = torch.nn.functional.normalize(torch.cat([proto[c] + 1.5 * torch.randn(n_per, d, generator=g) for c in range(C)]), dim=1)
+    yi = torch.arange(C).repeat_interleave(n_per)
+    return (xi, yi), draw(n_val), draw(n_val + 5), draw(n_txt), C
+
+
+def test_sweep_farm_equals_isolated_runs(tmp_path):
+    """Grid points run concurrently (one engine + HIP stream + host thread each, shared feature
+    tables) give exactly what each point gives when run alone with the same private generator."""
+    import types
+    import finetune as ft
+    from engine.datasets.utils import TextTensorDataset
+    from engine.models.head import UMLClip
+    tr, va, te, (xt, yt), C = _toy_dataset()
+    text_ds = TextTensorDataset(xt, yt, torch.zeros(len(yt), dtype=torch.long))
+    grid = {"optim": "adamw", "lr": [1e-3, 1e-4], "weight_decay": [0.0, 0.01, 0.001], "lr_scheduler": "cosine",
+            "batch_size": 16, "max_iter": 240, "warmup_iter": 50, "warmup_type": "linear", "warmup_min_lr": 1e-5,
+            "patience": 50, "dropout": None, "learnable_temp": False}
+    datasets = {"img_tr": tr, "img_val": va, "img_te": te, "text_ds": text_ds}
+
+    def args_for(path, workers):
+        os_path = str(path)
+        return types.SimpleNamespace(savepath=os_path, device=DEV, modality="crossmodal", alpha=1.0,
+                                     classifier_init="zeroshot", use_clip=True, logit=4.60517, nclasses=C, seed=3,
+                                     precision="fp32", sweep_workers=workers, eval_test=True)
+    (tmp_path / "farm").mkdir()
+    res, best_val, best_test = ft.sweep(datasets, grid, args_for(tmp_path / "farm", 4))
+    assert len(res["val_acc"]) == 6 and best_val == max(res["val_acc"])
+    for idx, hp in enumerate(ft._grid(grid)):
+        gen = torch.Generator()
+        gen.manual_seed(ft.farm_seed(3, idx))
+        torch.manual_seed(ft.farm_seed(3, idx))
+        model = UMLClip(tr[0].shape[1], C, logit_scale_init=4.60517, bias=False, learnable_temp=False)
+        solo = ft.setup_feature_run(tr, va, te, text_ds, hp, num_classes=C, use_clip=True, device=DEV, generator=gen,
+                                    model=model)
+        saved = torch.load(tmp_path / "farm" / ft.hparam_str(hp["optim"], hp["lr"], hp["weight_decay"], 16, 240, None, False)
+                           / "test_result.pth", weights_only=True)
+        assert saved["iter"] == solo["iter"]
+        assert saved["val_acc"] == solo["val_acc"] == res["val_acc"][idx]
+        assert saved["test_acc"] == solo["test_acc"] == res["test_acc"][idx]
+        assert torch.equal(saved["model"]["head.weight"], solo["model"]["head.weight"])
+    # a second sweep finds every result file and skips the work (reference finetune.py:330-333)
+    res2, _, _ = ft.sweep(datasets, grid, args_for(tmp_path / "farm", 4))
+    assert res2["val_acc"] == res["val_acc"]

@@ -106,8 +106,12 @@ class FeatureLoader:
     fused step); plain iteration yields the reference's batch containers."""
 
     def __init__(self, table: FeatureTable, batch_size, shuffle=False, drop_last=False, kind="image",
-                 order_rng="torch-cpu"):
+                 order_rng="torch-cpu", generator=None):
         assert kind in ("image", "text") and order_rng in ("torch-cpu", "device")
+        # generator: private torch.Generator the iterator/sampler seeds are drawn from instead of the
+        # global CPU generator (DataLoader's own ``generator=`` argument) -- concurrent sweep workers
+        # each own one, so their batch orders do not depend on thread interleaving
+        self.generator = generator
         self.table, self.batch_size, self.shuffle, self.drop_last, self.kind = table, int(batch_size), shuffle, drop_last, kind
         self.dataset = table
         # "torch-cpu": the reference's DataLoader order bit for bit (CPU mt19937 randperm + H2D per
@@ -140,7 +144,7 @@ class FeatureLoader:
 class _IndexIter:
     def __init__(self, loader: FeatureLoader):
         self.loader = loader
-        torch.empty((), dtype=torch.int64).random_()                      # DataLoader iterator base seed
+        torch.empty((), dtype=torch.int64).random_(generator=loader.generator)   # DataLoader iterator base seed
         self.order = None
         self.pos = 0
 
@@ -152,7 +156,7 @@ class _IndexIter:
         n, bs = len(ld.table), ld.batch_size
         if self.order is None:
             if ld.shuffle:
-                seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler seed
+                seed = int(torch.empty((), dtype=torch.int64).random_(generator=ld.generator).item())   # RandomSampler seed
                 if ld.order_rng == "device":
                     import umlh
                     self.order = umlh.random_permutation(n, seed, ld.table.device)   # one tiny kernel, no sort

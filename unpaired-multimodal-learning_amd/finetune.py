@@ -222,21 +222,35 @@ def hparam_str(optim, lr, wd, batch_size, iters, dropout, learnable_temp):
     return base
 
 
+def feature_tables(img_train, img_val, img_test, text_ds, device):
+    """The four device-resident tables of one dataset (uploaded once; a sweep shares them)."""
+    return {"train": FeatureTable(*img_train, device), "val": FeatureTable(*img_val, device),
+            "test": FeatureTable(*img_test, device),
+            "text": FeatureTable(text_ds.input_tensor, text_ds.label_tensor, device, text_ds.eot_indices)}
+
+
 def setup_feature_run(img_train, img_val, img_test, text_ds, hparams, *, num_classes, modality="crossmodal",
                       alpha=1.0, classifier_init="zeroshot", use_clip=False, clip_logit=4.60517, text_indim=None,
-                      device="cuda:0", eval_test=True, precision="fp32", eval_freq=EVAL_FREQ):
+                      device="cuda:0", eval_test=True, precision="fp32", eval_freq=EVAL_FREQ, tables=None,
+                      generator=None, order_rng="torch-cpu", model=None):
     """``setup()`` (finetune.py:323-404) for pre-extracted features: builds the model,
     optimizer, scheduler and the four loaders with the reference's wiring, trains, tests.
 
-    img_* are (features [N,d], labels [N]) pairs; text_ds a TextTensorDataset."""
+    img_* are (features [N,d], labels [N]) pairs; text_ds a TextTensorDataset.  ``tables`` (from
+    ``feature_tables``), ``generator`` (private seed source of the loaders) and a pre-built ``model``
+    are what the concurrent sweep passes in."""
     d_img = img_train[0].shape[1]
     d_txt = text_ds.input_tensor.shape[1]
-    if use_clip:
+    if model is not None:
+        pass
+    elif use_clip:
         model = UMLClip(d_img, num_classes, logit_scale_init=clip_logit, bias=False,
                         learnable_temp=hparams["learnable_temp"])
     else:
         tin = (d_txt if text_indim is None else text_indim) if modality == "crossmodal" else (text_indim or 0)
         model = UML(d_img, tin, num_classes, bias=False, learnable_temp=hparams["learnable_temp"])
+    if tables is None:
+        tables = feature_tables(img_train, img_val, img_test, text_ds, device)
     model.to(device)
     if classifier_init == "zeroshot" and (modality == "crossmodal" or model.shared_dim == d_txt):
         model.zero_shot_init(text_ds)
@@ -244,15 +258,15 @@ def setup_feature_run(img_train, img_val, img_test, text_ds, hparams, *, num_cla
     scheduler = build_lr_scheduler(optimizer, hparams["lr_scheduler"], hparams["warmup_iter"], hparams["max_iter"],
                                    warmup_type=hparams["warmup_type"], warmup_lr=hparams["warmup_min_lr"])
     bs = hparams["batch_size"]
-    image_loader = FeatureLoader(FeatureTable(*img_train, device), bs, shuffle=True, kind="image")
-    text_loader = FeatureLoader(FeatureTable(text_ds.input_tensor, text_ds.label_tensor, device, text_ds.eot_indices),
-                                bs, shuffle=True, kind="text")
+    kw = {"order_rng": order_rng, "generator": generator}
+    image_loader = FeatureLoader(tables["train"], bs, shuffle=True, kind="image", **kw)
+    text_loader = FeatureLoader(tables["text"], bs, shuffle=True, kind="text", **kw)
     if modality == "image":
         text_loader = None
     elif modality == "text":
         image_loader = None
-    val_loader = FeatureLoader(FeatureTable(*img_val, device), bs, shuffle=False, kind="image")
-    test_loader = FeatureLoader(FeatureTable(*img_test, device), bs, shuffle=False, kind="image")
+    val_loader = FeatureLoader(tables["val"], bs, shuffle=False, kind="image", **kw)
+    test_loader = FeatureLoader(tables["test"], bs, shuffle=False, kind="image", **kw)
     result = train(model, image_loader, text_loader, val_loader, test_loader if eval_test else None, optimizer,
                    scheduler, device=device, max_iters=hparams["max_iter"], alpha=alpha, eval_freq=eval_freq,
                    patience=hparams["patience"], precision=precision)
@@ -309,25 +323,109 @@ def setup(datasets, hparams, args):
     return test_dict
 
 
-def sweep(datasets, hyperparams, args):
-    """Cartesian product over the list-valued entries of a HYPER_DICT grid, in key order
-    (reference :406-448); returns (results, best_val_acc, best_test_acc)."""
+def _grid(hyperparams):
     from itertools import product
     grid = {k: (v if isinstance(v, list) else [v]) for k, v in hyperparams.items()}
     keys = list(grid)
-    results = {"test_acc": [], "val_acc": [], "hparams": [], "model_records": []}
-    for idx, combo in enumerate(product(*[grid[k] for k in keys])):
-        hp = dict(zip(keys, combo))
-        print(f"=> Running {idx + 1}: {hp}")
-        out = setup(datasets, hp, args)
-        results["test_acc"].append(out["test_acc"])
-        results["val_acc"].append(out["val_acc"])
-        results["hparams"].append(hp)
+    return [dict(zip(keys, combo)) for combo in product(*[grid[k] for k in keys])]
+
+
+def _report(results, args):
     torch.save(results, os.path.join(args.savepath, "results.pth"))
     best = int(torch.argmax(torch.tensor(results["val_acc"])))
     print(f"=> [FINAL] Best Val Acc: {results['val_acc'][best]:.4f} | Best Test Acc: {results['test_acc'][best]:.4f}")
     print(f"=> [FINAL] Best Hyperparameters: {results['hparams'][best]}")
     return results, results["val_acc"][best], results["test_acc"][best]
+
+
+def sweep(datasets, hyperparams, args):
+    """Cartesian product over the list-valued entries of a HYPER_DICT grid, in key order
+    (reference :406-448); returns (results, best_val_acc, best_test_acc).
+
+    ``args.sweep_workers > 1`` runs the grid points concurrently on one GPU (``sweep_farm``)."""
+    if int(getattr(args, "sweep_workers", 1) or 1) > 1:
+        return sweep_farm(datasets, hyperparams, args, int(args.sweep_workers))
+    results = {"test_acc": [], "val_acc": [], "hparams": [], "model_records": []}
+    for idx, hp in enumerate(_grid(hyperparams)):
+        print(f"=> Running {idx + 1}: {hp}")
+        out = setup(datasets, hp, args)
+        results["test_acc"].append(out["test_acc"])
+        results["val_acc"].append(out["val_acc"])
+        results["hparams"].append(hp)
+    return _report(results, args)
+
+
+def farm_seed(base_seed, idx):
+    """Seed of grid point ``idx``'s private generator (loader orders) and of its model init."""
+    return (int(base_seed) if base_seed is not None and int(base_seed) >= 0 else 0) * 100003 + 7919 * (idx + 1)
+
+
+def sweep_farm(datasets, hyperparams, args, workers):
+    """The sweep as a farm: the grid points of one dataset are independent head fine-tunes over the
+    SAME feature tables (18 AdamW points in ``clip_linear``), each far too small to fill 256 CUs
+    (batch 32: a handful of workgroups per kernel).  The tables are uploaded once; every grid point
+    gets its own engine, its own HIP stream and a host thread that enqueues whole evaluation
+    intervals through ``umlh_train_steps`` (a C loop, no GIL), so the small kernels of different
+    points overlap on the chip.  No collective, no shared mutable state.
+
+    Unlike the sequential sweep -- where point k's shuffles depend on how much global RNG the
+    points before it consumed -- every point draws from a private generator seeded by
+    ``farm_seed(args.seed, k)``: results are reproducible and independent of scheduling, but not
+    batch-for-batch those of the sequential order (``sweep_workers=1`` keeps that)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from engine.models.head import UML, UMLClip
+    points = _grid(hyperparams)
+    dev = torch.device(args.device)
+    tables = feature_tables(datasets["img_tr"], datasets["img_val"], datasets["img_te"], datasets["text_ds"], dev)
+    if getattr(args, "precision", "fp32") == "bf16":
+        for t in tables.values():
+            t.features_bf16()
+    d_img, d_txt = tables["train"].features.shape[1], tables["text"].features.shape[1]
+    text_indim = getattr(args, "text_indim", None) if args.modality == "crossmodal" else getattr(args, "common_dim", 0)
+    jobs = []
+    for idx, hp in enumerate(points):                      # models built here, in order: deterministic inits
+        ckpt_dir = os.path.join(args.savepath, hparam_str(hp["optim"], hp["lr"], hp["weight_decay"], hp["batch_size"],
+                                                          hp["max_iter"], hp["dropout"], hp["learnable_temp"]))
+        os.makedirs(ckpt_dir, exist_ok=True)
+        test_path = os.path.join(ckpt_dir, "test_result.pth")
+        if os.path.exists(test_path) and not FLAG:
+            jobs.append((idx, hp, test_path, None))
+            continue
+        torch.manual_seed(farm_seed(args.seed, idx))
+        if args.use_clip:
+            model = UMLClip(d_img, args.nclasses, logit_scale_init=args.logit, bias=False, learnable_temp=hp["learnable_temp"])
+        else:
+            tin = (d_txt if text_indim is None else text_indim) if args.modality == "crossmodal" else (text_indim or 0)
+            model = UML(d_img, tin, args.nclasses, bias=False, learnable_temp=hp["learnable_temp"])
+        jobs.append((idx, hp, test_path, model))
+    main_stream = torch.cuda.current_stream(dev)
+
+    def run(job):
+        idx, hp, test_path, model = job
+        if model is None:
+            print(f"=> Skipping {os.path.dirname(test_path)} as it already exists!")
+            return torch.load(test_path, map_location="cpu", weights_only=True)
+        gen = torch.Generator()
+        gen.manual_seed(farm_seed(args.seed, idx))
+        stream = torch.cuda.Stream(dev)
+        stream.wait_stream(main_stream)                    # the shared tables were uploaded there
+        with torch.cuda.stream(stream):
+            res = setup_feature_run(datasets["img_tr"], datasets["img_val"], datasets["img_te"], datasets["text_ds"], hp,
+                                    num_classes=args.nclasses, modality=args.modality, alpha=args.alpha,
+                                    classifier_init=args.classifier_init, use_clip=args.use_clip, clip_logit=args.logit,
+                                    text_indim=text_indim, device=dev, eval_test=getattr(args, "eval_test", True),
+                                    precision=getattr(args, "precision", "fp32"), tables=tables, generator=gen,
+                                    order_rng=getattr(args, "order_rng", "torch-cpu"), model=model)
+            stream.synchronize()
+        test_dict = {"test_acc": res["test_acc"], "val_acc": res["val_acc"], "model": res["model"], "iter": res["iter"]}
+        torch.save(test_dict, test_path)
+        return test_dict
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        outs = list(pool.map(run, jobs))
+    results = {"test_acc": [o["test_acc"] for o in outs], "val_acc": [o["val_acc"] for o in outs],
+               "hparams": points, "model_records": []}
+    return _report(results, args)
 
 
 def main(args):
