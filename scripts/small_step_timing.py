@@ -16,7 +16,7 @@ e = umlh.HeadEngine(d, d, C, optimizer="adamw", weight_decay=0.01, max_rows_img=
 e.w_head.normal_(0, 0.05); e.scales.fill_(100.0)
 n = 100
 tab = (x, y, x16) if prec == "bf16" else (x, y)
-for rep in range(4):
+for rep in range(int(sys.argv[3]) if len(sys.argv) > 3 else 4):
     bi = [torch.randint(0, 4096, (B,), generator=g, device=DEV) for _ in range(n)]
     bt = [torch.randint(0, 4096, (B,), generator=g, device=DEV) for _ in range(n)]
     sc = torch.zeros(n, umlh.N_SCALARS, device=DEV)

@@ -145,11 +145,17 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     auto wfrag = [&](int ks, int ct) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(wlane + ((size_t)ks * (CPAD / 32) + ct) * 512);
     };
+    // a wave whose sample rows all lie past the segment (batch 32 in a 64-row block) or whose classes are all
+    // padding neither streams W nor issues MFMAs (wave-uniform); its accumulators stay 0 and are masked below
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool live = row0 + (wave_u / WC) * 32 * STW < sg.rows && (wave_u % WC) * CTW * 32 < C;
     bf16x8 ring[PD][CTW];
+    if (live) {
 #pragma unroll
-    for (int d = 0; d < PD; ++d)
+        for (int d = 0; d < PD; ++d)
 #pragma unroll
-        for (int ct = 0; ct < CTW; ++ct) ring[d][ct] = wfrag(min(d, nks - 1), ct);
+            for (int ct = 0; ct < CTW; ++ct) ring[d][ct] = wfrag(min(d, nks - 1), ct);
+    }
 
     STAMP(1);
     for (int kb0 = 0; kb0 < ((a.dbg == 2 || a.dbg == 5) ? 0 : K); kb0 += XK) {
@@ -203,8 +209,10 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         };
         const bool last_block = kb0 + XK >= K;
         const int nfull = last_block ? nst - PD : nst;
-        for (int s = 0; s < nfull; s += PD) kgroup(s, std::true_type{});
-        if (last_block) kgroup(nst - PD, std::false_type{});
+        if (live) {
+            for (int s = 0; s < nfull; s += PD) kgroup(s, std::true_type{});
+            if (last_block) kgroup(nst - PD, std::false_type{});
+        }
     }
 
     STAMP(2);
