@@ -111,12 +111,99 @@ def test_bf16_eval_batch():
     assert abs(sc[umlh.S_CORRECT] - O.top1_correct(z, yi).sum()) <= 2
 
 
-def test_bf16_requires_linear_head_and_k_multiple_of_32():
+def test_bf16_shape_requirements():
     import umlh
     with pytest.raises(umlh.UmlhError):
-        umlh.HeadEngine(48, 64, 10, has_proj=True, precision="bf16", device=DEV)
+        umlh.HeadEngine(48, 128, 10, has_proj=True, precision="bf16", device=DEV)      # d_img % 64
     with pytest.raises(umlh.UmlhError):
-        umlh.HeadEngine(96, 96, 10, precision="bf16", device=DEV)
+        umlh.HeadEngine(96, 96, 10, precision="bf16", device=DEV)                       # d_shared % 128
+
+
+@pytest.mark.parametrize("d_img,d_sh,C,bi,bt,learn,use_idx", [(64, 128, 10, 70, 33, False, True), (128, 256, 100, 300, 257, True, True),
+                                                              (192, 128, 37, 64, 0, False, False), (1024, 384, 1000, 130, 90, False, True)])
+def test_bf16_two_layer_head_grad_step(d_img, d_sh, C, bi, bt, learn, use_idx):
+    """bf16 mode with img_proj (head.py:64-66,79): H = X W_proj^T, fused forward on H, dW_head, dH^T, dW_proj all
+    through the bf16 GEMM kernels; against the oracle on bf16-rounded operands (H, dZ and dH are additionally
+    rounded on the device) and loosely against the exact fp32 oracle."""
+    import umlh
+    rng = np.random.default_rng(d_img + d_sh + C)
+    n_i, n_t = 400, 350
+    xi = rng.standard_normal((n_i, d_img)).astype(np.float32)
+    xi /= np.linalg.norm(xi, axis=1, keepdims=True)
+    xt = rng.standard_normal((n_t, d_sh)).astype(np.float32)
+    xt /= np.linalg.norm(xt, axis=1, keepdims=True)
+    wp = (rng.standard_normal((d_sh, d_img)) / np.sqrt(d_img)).astype(np.float32)
+    wh = rng.standard_normal((C, d_sh)).astype(np.float32)
+    wh /= np.linalg.norm(wh, axis=1, keepdims=True)
+    yi, yt = rng.integers(0, C, n_i), rng.integers(0, C, n_t)
+    si, stx = 8.0, 5.0
+    e = umlh.HeadEngine(d_img, d_sh, C, has_proj=True, learnable_temp=learn, optimizer="adamw", max_rows_img=512,
+                        max_rows_txt=512, precision="bf16", device=DEV)
+    e.w_head.copy_(torch.from_numpy(wh)); e.w_proj.copy_(torch.from_numpy(wp))
+    e.scales.copy_(torch.tensor([si, stx]))
+    if use_idx:
+        ii, ti = rng.permutation(n_i)[:bi], (rng.permutation(n_t)[:bt] if bt else None)
+        bi_rb, bt_rb = _rb(xi, yi, ii), (_rb(xt, yt, ti) if bt else None)
+        xi_b, yi_b = xi[ii], yi[ii]
+        xt_b, yt_b = (xt[ti], yt[ti]) if bt else (None, None)
+    else:
+        bi_rb, bt_rb = _rb(xi[:bi], yi[:bi]), (_rb(xt[:bt], yt[:bt]) if bt else None)
+        xi_b, yi_b = xi[:bi], yi[:bi]
+        xt_b, yt_b = (xt[:bt], yt[:bt]) if bt else (None, None)
+    flat = e.grad_step(bi_rb, bt_rb, alpha=0.7)
+    torch.cuda.synchronize()
+    f = flat.cpu().numpy()
+    nh, npj = C * d_sh, d_sh * d_img
+    gh, gp, gs, sc = f[:nh].reshape(C, d_sh), f[nh:nh + npj].reshape(d_sh, d_img), f[nh + npj:nh + npj + 2], f[nh + npj + 2:]
+    for rounded, tol_l, tol_g in ((True, 2e-2, 4e-2), (False, 6e-2, 8e-2)):
+        R = _bf16_round if rounded else (lambda a: a)
+        st = O.HeadState(R(wh), R(wp), si, stx, learn)
+        so = O.step_grads(st, R(xi_b), yi_b, R(xt_b) if bt else None, yt_b, 0.7)
+        assert abs(sc[umlh.S_LOSS_IMG] - so.loss_img) < tol_l * max(1.0, so.loss_img)
+        if bt:
+            assert abs(sc[umlh.S_LOSS_TXT] - so.loss_txt) < tol_l * max(1.0, so.loss_txt)
+        for got, key in ((gh, "w_head"), (gp, "w_proj")):
+            ref = so.grads[key]
+            assert np.abs(got - ref).max() < tol_g * np.abs(ref).max(), key
+        if learn:
+            assert abs(gs[0] - float(so.grads["img_scale"])) < tol_g * max(1e-3, abs(float(so.grads["img_scale"])))
+
+
+def test_bf16_two_layer_head_training_tracks_fp32():
+    """60 AdamW steps of the 2-layer head in bf16 mode vs fp32 mode on the same batches: same loss curve
+    (2e-2) and weights within bf16 noise."""
+    import umlh
+    rng = np.random.default_rng(3)
+    d_img, d_sh, C, n = 128, 256, 50, 2000
+    proto_i, proto_t = rng.standard_normal((C, d_img)), rng.standard_normal((C, d_sh))
+    yi, yt = rng.integers(0, C, n), rng.integers(0, C, n)
+    xi = (proto_i[yi] + 2.0 * rng.standard_normal((n, d_img))).astype(np.float32)
+    xt = (proto_t[yt] + 2.0 * rng.standard_normal((n, d_sh))).astype(np.float32)
+    xi /= np.linalg.norm(xi, axis=1, keepdims=True); xt /= np.linalg.norm(xt, axis=1, keepdims=True)
+    wp = (rng.standard_normal((d_sh, d_img)) / np.sqrt(d_img)).astype(np.float32)
+    wh = (0.05 * rng.standard_normal((C, d_sh))).astype(np.float32)
+    T = lambda a, t=torch.float32: torch.as_tensor(a).to(DEV, t).contiguous()
+    Xi, Yi, Xt, Yt = T(xi), T(yi, torch.int64), T(xt), T(yt, torch.int64)
+    tabs = {"fp32": ((Xi, Yi), (Xt, Yt)), "bf16": ((Xi, Yi, umlh.to_bf16(Xi)), (Xt, Yt, umlh.to_bf16(Xt)))}
+    steps, B = 60, 128
+    g = torch.Generator().manual_seed(0)
+    bi = [torch.randint(0, n, (B,), generator=g).to(DEV) for _ in range(steps)]
+    bt = [torch.randint(0, n, (B,), generator=g).to(DEV) for _ in range(steps)]
+    out = {}
+    for prec in ("fp32", "bf16"):
+        e = umlh.HeadEngine(d_img, d_sh, C, has_proj=True, optimizer="adamw", weight_decay=0.01, max_rows_img=B,
+                            max_rows_txt=B, precision=prec, device=DEV)
+        e.w_head.copy_(T(wh)); e.w_proj.copy_(T(wp)); e.scales.fill_(10.0)
+        sc = torch.zeros(steps, umlh.N_SCALARS, device=DEV)
+        e.train_steps(tabs[prec][0], bi, tabs[prec][1], bt, [2e-3] * steps, first_step=1, scalars_out=sc)
+        torch.cuda.synchronize()
+        out[prec] = (sc.cpu().numpy(), e.w_head.cpu().numpy().copy(), e.w_proj.cpu().numpy().copy())
+    l32, l16 = out["fp32"][0], out["bf16"][0]
+    assert l32[-1, umlh.S_LOSS_IMG] < 0.8 * l32[0, umlh.S_LOSS_IMG]                    # it trains
+    np.testing.assert_allclose(l16[:, umlh.S_LOSS_IMG], l32[:, umlh.S_LOSS_IMG], atol=3e-2)
+    np.testing.assert_allclose(l16[:, umlh.S_LOSS_TXT], l32[:, umlh.S_LOSS_TXT], atol=3e-2)
+    for k in (1, 2):
+        assert np.abs(out["bf16"][k] - out["fp32"][k]).max() < 0.1 * np.abs(out["fp32"][k]).max()
 
 
 def test_bf16_training_accuracy_parity_with_fp32():

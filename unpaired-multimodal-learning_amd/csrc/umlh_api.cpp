@@ -31,7 +31,8 @@ int umlh_launch_iota(long long* dst, long long n, hipStream_t stream);
 
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
-int umlh_bf16_launch_dw(const DwArgsB* g, int splits, hipStream_t stream);
+int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream);
+int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, void* dst, int mode, hipStream_t stream);
 }
 
 static thread_local char g_err[512] = "";
@@ -47,7 +48,8 @@ static int fail(int code, const char* fmt, ...) {
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 struct Layout {                 // workspace partition, in floats from the base
-    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, iota, zeros, dbg, total;
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, iota, zeros, dbg, wpt16, wht16, total;
+    long long n_iota;
     int rcap_img, rcap_txt, ldz;     // padded row capacities
     int scap_head, scap_proj;        // split-K slab capacities
     long long n_head, n_proj;        // parameter counts
@@ -91,8 +93,9 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     if (c.max_rows_img < 0 || c.max_rows_txt < 0 || c.max_rows_img + c.max_rows_txt < 1) return false;
     if (c.optimizer < UMLH_OPT_SGD || c.optimizer > UMLH_OPT_ADAMW) return false;
     if (c.precision != UMLH_PREC_FP32 && c.precision != UMLH_PREC_BF16) return false;
-    // bf16 mode: linear head only (img_proj GEMMs run in fp32 mode), K a multiple of the 32-wide chunk
-    if (c.precision == UMLH_PREC_BF16 && (c.has_proj || c.d_shared % 128 != 0)) return false;
+    // bf16 mode: the shared dim is the K of the fused forward (X tile staged in 128-wide K blocks); with img_proj the
+    // image width is the K of H = X W_proj^T, whose row-major A operand is read in whole 64-wide chunks
+    if (c.precision == UMLH_PREC_BF16 && (c.d_shared % 128 != 0 || (c.has_proj && c.d_img % 64 != 0))) return false;
     L.rcap_img = (int)round_up(c.max_rows_img, 256);
     L.rcap_txt = (int)round_up(c.max_rows_txt, 256);
     L.ldz = L.rcap_img + L.rcap_txt;
@@ -101,6 +104,7 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     L.scap_head = split_cap(c.num_classes, c.d_shared);
     if (c.precision == UMLH_PREC_BF16 && L.scap_head < (L.ldz + 4095) / 4096 + 1) L.scap_head = (L.ldz + 4095) / 4096 + 1;
     L.scap_proj = c.has_proj ? split_cap(c.d_shared, c.d_img) : 0;
+    if (c.has_proj && c.precision == UMLH_PREC_BF16 && L.scap_proj < (L.rcap_img + 4095) / 4096) L.scap_proj = (L.rcap_img + 4095) / 4096;
     L.max_blocks = L.ldz / 32 + 2;
     long long off = 0;
     auto take = [&](long long n) { long long o = off; off += round_up(n, 64); return o; };
@@ -114,9 +118,15 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     L.partials = take((long long)L.max_blocks * 4);
     L.grads = take(L.n_head + L.n_proj + 2 + UMLH_N_SCALARS);
     L.w16 = take(c.precision == UMLH_PREC_BF16 ? 1024LL * c.d_shared / 2 : 0);   // bf16 chunk-major shadow of w_head (<= 1024 class rows)
-    L.iota = take(c.precision == UMLH_PREC_BF16 ? 2LL * (L.rcap_img > L.rcap_txt ? L.rcap_img : L.rcap_txt) : 0);   // int64 0..cap-1
+    L.n_iota = L.rcap_img > L.rcap_txt ? L.rcap_img : L.rcap_txt;     // identity row ids: batch rows, classes, image-feature columns
+    if (L.n_iota < 1024) L.n_iota = 1024;
+    if (L.n_iota < c.d_img) L.n_iota = c.d_img;
+    L.iota = take(c.precision == UMLH_PREC_BF16 ? 2LL * L.n_iota : 0);   // int64 0..n_iota-1
     L.zeros = take(64);
     L.dbg = take((long long)L.max_blocks * 128);         // diagnostic stamps: [blocks][8 waves][8] u64
+    const bool bfp = c.precision == UMLH_PREC_BF16 && c.has_proj;
+    L.wpt16 = take(bfp ? (L.n_proj + 1) / 2 : 0);         // bf16 W_proj^T [d_img][d_shared]
+    L.wht16 = take(bfp ? 1024LL * round_up(c.d_shared, 128) / 2 : 0);   // bf16 W_head^T by class chunks [16][d_shared^128][64]
     L.total = off;
     return true;
 }
@@ -426,7 +436,42 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             return fail(UMLH_E_INVALID, "bf16 mode: batch.feats_bf16 is required (umlh_to_bf16 of the feature table)");
         u16* w16 = reinterpret_cast<u16*>(ws(h, L.w16));
         u16* dz16 = reinterpret_cast<u16*>(dzt);
+        u16* h16 = reinterpret_cast<u16*>(H);                                  // bf16 H = X W_proj^T, row-major [r][d_shared]
+        u16* dht16 = reinterpret_cast<u16*>(ws(h, L.dht));                     // bf16 dH^T, chunk-major [r/64][d_shared^128][64]
+        const u16* zeros16 = reinterpret_cast<const u16*>(ws(h, L.zeros));
+        const int dsp = (int)round_up(c.d_shared, 128);
+        const bool proj = c.has_proj && ri > 0;
         mark(h, 0, st);
+        // the GEMM loaders are branch-free: every pointer must be dereferenceable, also for an absent
+        // modality or a dense (index-less) batch -> identity row ids + a zero page from the workspace
+        int64_t* iota = reinterpret_cast<int64_t*>(ws(h, L.iota));
+        if (!h->iota_ready) {
+            HIPCHK(umlh_launch_iota(reinterpret_cast<long long*>(iota), L.n_iota, st), "iota");
+            HIPCHK((int)hipMemsetAsync(ws(h, L.zeros), 0, 64 * sizeof(float), st), "zero page");
+            h->iota_ready = true;
+        }
+        auto base_args = [&]() {
+            DwArgsB g;
+            memset(&g, 0, sizeof(g));
+            g.zeros = zeros16; g.bcs = 64; g.a_rows = iota; g.nsplit = g.nsplit1 = 1;
+            { const char* e = getenv("UMLH_DBG_DW"); g.dbg = e ? atoi(e) : 0; }
+            if (g.dbg >= 16) { g.dbg -= 16; g.stamps = reinterpret_cast<unsigned long long*>(ws(h, L.dbg)); }   // +16: cycle stamps
+            return g;
+        };
+        if (proj) {
+            // H = X_img W_proj^T  (head.py:79): rows gathered by the batch index, bf16 out.  W_proj^T is a
+            // per-step bf16 shadow of the fp32 master (6.5 MB at cfg3, against ~180 GFLOP of GEMMs per step).
+            u16* wpt16 = reinterpret_cast<u16*>(ws(h, L.wpt16));
+            HIPCHK(umlh_bf16_launch_transpose_shadow(h->buf.w_proj, c.d_shared, c.d_img, c.d_shared, wpt16, 0, st), "W_proj^T shadow");
+            DwArgsB g = base_args();
+            g.A = static_cast<const u16*>(img->feats_bf16); g.lda = c.d_img; g.a_rows = img->index ? img->index : iota;
+            g.B = g.B2 = wpt16; g.k_rows = g.k_rows2 = iota; g.ldb = g.ldb2 = c.d_shared;
+            g.M = ri; g.N = c.d_shared; g.K = c.d_img;
+            g.k_chunk = (int)round_up(c.d_img, 256); g.k_switch = c.d_img; g.k_valid1 = c.d_img; g.k_valid2 = 0;
+            g.out16 = h16; g.ldo = c.d_shared;
+            if (g.k_chunk > 4096) return fail(UMLH_E_INVALID, "bf16 img_proj: d_img %d > 4096 unsupported", c.d_img);
+            HIPCHK(umlh_bf16_launch_dw(&g, 1, 1, 1, st), "proj forward (bf16)");
+        }
         // bf16 shadow of the fp32 master weight, refreshed every call (the caller may have
         // rewritten w_head: load_state_dict, zero-shot init)
         const int cpad = 32 * h->ctw * h->wc;
@@ -442,7 +487,8 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         SegDescB& b0 = fb.seg[0];
         SegDescB& b1 = fb.seg[1];
         if (ri > 0) {
-            b0.feats = static_cast<const u16*>(img->feats_bf16); b0.feat_index = img->index;
+            b0.feats = proj ? h16 : static_cast<const u16*>(img->feats_bf16);
+            b0.feat_index = proj ? nullptr : img->index;
             b0.labels = img->labels; b0.label_index = img->index; b0.ld = c.d_shared; b0.rows = ri;
             b0.w_over_rows = hy->img_alpha / (float)img->global_rows;
         }
@@ -464,39 +510,57 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         mark(h, 2, st);
         *n_slabs_head = 0; *n_slabs_proj = 0;
         if (!want_grad) return UMLH_OK;
-        const int rcols_b = r0p + r1p;
-        // chunk: multiples of 4 x 64 columns (4-stage pipeline), at most 4096 (row ids of a split live in LDS)
-        SplitPlan sp = plan_splits(r0p, r1p, L.scap_head, 256, 256);
-        if (sp.chunk > 4096) { sp.chunk = 4096; sp.n_img = (r0p + 4095) / 4096; sp.n_txt = (r1p + 4095) / 4096; }
-        const int chunk = sp.chunk, splits = sp.n_img + sp.n_txt;
-        if (splits > L.scap_head)
-            return fail(UMLH_E_INVALID, "bf16 dW: %d + %d reduction rows need more than %d split-K slabs", r0p, r1p, L.scap_head);
-        // the dW loader is branch-free: every pointer must be dereferenceable, also for an absent
-        // modality or a dense (index-less) batch -> identity row ids from the workspace
-        int64_t* iota = reinterpret_cast<int64_t*>(ws(h, L.iota));
-        if (!h->iota_ready) {
-            long long n = L.rcap_img > L.rcap_txt ? L.rcap_img : L.rcap_txt;
-            HIPCHK(umlh_launch_iota(reinterpret_cast<long long*>(iota), n, st), "iota");
-            HIPCHK((int)hipMemsetAsync(ws(h, L.zeros), 0, 64 * sizeof(float), st), "zero page");
-            h->iota_ready = true;
+        // ---- dW_head = dZ^T [H or X_img ; X_txt] ----
+        {
+            // chunk: multiples of 4 x 64 columns (4-stage pipeline), at most 4096 (row ids of a split live in LDS)
+            SplitPlan sp = plan_splits(r0p, r1p, L.scap_head, 256, 256);
+            if (sp.chunk > 4096) { sp.chunk = 4096; sp.n_img = (r0p + 4095) / 4096; sp.n_txt = (r1p + 4095) / 4096; }
+            const int splits = sp.n_img + sp.n_txt;
+            if (splits > L.scap_head)
+                return fail(UMLH_E_INVALID, "bf16 dW: %d + %d reduction rows need more than %d split-K slabs", r0p, r1p, L.scap_head);
+            const u16* any16 = ri > 0 ? static_cast<const u16*>(img->feats_bf16) : static_cast<const u16*>(txt->feats_bf16);
+            DwArgsB g = base_args();
+            g.A = dz16; g.lda = crows;
+            g.B = proj ? h16 : (ri > 0 ? static_cast<const u16*>(img->feats_bf16) : any16);
+            g.k_rows = (ri > 0 && img->index && !proj) ? img->index : iota; g.ldb = c.d_shared;
+            g.B2 = rt > 0 ? static_cast<const u16*>(txt->feats_bf16) : any16;
+            g.k_rows2 = (rt > 0 && txt->index) ? txt->index : iota; g.ldb2 = c.d_shared;
+            g.out = ws(h, L.slabs_head); g.ldo = c.d_shared;
+            g.M = c.num_classes; g.N = c.d_shared; g.K = r0p + r1p;
+            g.k_chunk = sp.chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
+            g.nsplit = splits; g.nsplit1 = sp.n_img; h->n_slabs_img = sp.n_img;
+            HIPCHK(umlh_bf16_launch_dw(&g, splits, 0, 0, st), "dw_bf16");
+            *n_slabs_head = splits;
         }
-        const u16* any16 = ri > 0 ? static_cast<const u16*>(img->feats_bf16) : static_cast<const u16*>(txt->feats_bf16);
-        DwArgsB g;
-        memset(&g, 0, sizeof(g));
-        g.A = dz16; g.lda = crows; g.zeros = reinterpret_cast<const u16*>(ws(h, L.zeros));
-        g.B = ri > 0 ? static_cast<const u16*>(img->feats_bf16) : any16;
-        g.k_rows = (ri > 0 && img->index) ? img->index : iota; g.ldb = c.d_shared;
-        g.B2 = rt > 0 ? static_cast<const u16*>(txt->feats_bf16) : any16;
-        g.k_rows2 = (rt > 0 && txt->index) ? txt->index : iota; g.ldb2 = c.d_shared;
-        g.out = ws(h, L.slabs_head); g.ldo = c.d_shared;
-        g.M = c.num_classes; g.N = c.d_shared; g.K = rcols_b;
-        g.k_chunk = chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
-        g.nsplit = splits; g.nsplit1 = sp.n_img; h->n_slabs_img = sp.n_img;
-        { const char* e = getenv("UMLH_DBG_DW"); g.dbg = e ? atoi(e) : 0; }
-        if (g.dbg >= 16) { g.dbg -= 16; g.stamps = reinterpret_cast<unsigned long long*>(ws(h, L.dbg)); }   // +16: cycle stamps
-        HIPCHK(umlh_bf16_launch_dw(&g, splits, st), "dw_bf16");
-        *n_slabs_head = splits;
         mark(h, 3, st);
+        if (proj) {
+            // dH^T[n][r] = sum_c W_head[c][n] dZ^T[c][r]  (image columns), bf16 chunk-major out
+            u16* wht16 = reinterpret_cast<u16*>(ws(h, L.wht16));
+            HIPCHK(umlh_bf16_launch_transpose_shadow(h->buf.w_head, c.num_classes, c.d_shared, dsp, wht16, 1, st), "W_head^T shadow");
+            const int kc = (int)round_up(c.num_classes, 64);
+            DwArgsB g = base_args();
+            g.A = wht16; g.lda = dsp;
+            g.B = g.B2 = dz16; g.k_rows = g.k_rows2 = iota; g.ldb = g.ldb2 = 64; g.bcs = crows * 64;
+            g.M = c.d_shared; g.N = r0p; g.K = kc;
+            g.k_chunk = (int)round_up(kc, 256); g.k_switch = kc; g.k_valid1 = c.num_classes; g.k_valid2 = 0;
+            g.out16 = dht16; g.ldo = dsp;
+            HIPCHK(umlh_bf16_launch_dw(&g, 1, 0, 2, st), "dH^T (bf16)");
+            // dW_proj[n][k] = sum_r dH^T[n][r] X_img[r][k]
+            SplitPlan sp = plan_splits(r0p, 0, L.scap_proj, 256, 256);
+            if (sp.chunk > 4096) { sp.chunk = 4096; sp.n_img = (r0p + 4095) / 4096; }
+            if (sp.n_img > L.scap_proj)
+                return fail(UMLH_E_INVALID, "bf16 dW_proj: %d reduction rows need more than %d split-K slabs", r0p, L.scap_proj);
+            DwArgsB p = base_args();
+            p.A = dht16; p.lda = dsp;
+            p.B = p.B2 = static_cast<const u16*>(img->feats_bf16); p.k_rows = p.k_rows2 = img->index ? img->index : iota;
+            p.ldb = p.ldb2 = c.d_img;
+            p.M = c.d_shared; p.N = c.d_img; p.K = r0p;
+            p.k_chunk = sp.chunk; p.k_switch = r0p; p.k_valid1 = ri; p.k_valid2 = 0;
+            p.out = ws(h, L.slabs_proj); p.ldo = c.d_img; p.slab_stride = L.n_proj;
+            p.nsplit = p.nsplit1 = sp.n_img;
+            HIPCHK(umlh_bf16_launch_dw(&p, sp.n_img, 0, 0, st), "dW_proj (bf16)");
+            *n_slabs_proj = sp.n_img;
+        }
         mark(h, 4, st);
         return UMLH_OK;
     }

@@ -86,8 +86,12 @@ struct FwdArgsB {
     float* diag_zero;            // 4 floats zeroed by block 0 (gradient-diagnostic accumulators of this step), or NULL
 };
 
+// bf16 GEMM out[m][n] = sum_k A[m][k] * B[k][n] (kernel dw_bf16<AM, OM>).  Written for dW = dZ^T F; the 2-layer
+// head's projection forward / dH^T / dW_proj reuse it through the A-source and output modes.
+//   AM 0: A column-chunk-major [K/64][lda][64] (k contiguous inside a chunk)     AM 1: A row-major, row m at A + a_rows[m]*lda
+//   OM 0: fp32 split-K slabs   OM 1: bf16 row-major out[m*ldo + n]   OM 2: bf16 chunk-major out[((n>>6)*ldo + m)*64 + (n&63)]
 struct DwArgsB {
-    const u16* A;                // dZ^T bf16, column-chunk-major [K/64][lda=crows][64]
+    const u16* A;                // AM 0: dZ^T-style chunk-major; AM 1: row-major rows gathered by a_rows
     const u16* B;  const int64_t* k_rows;  int ldb;     // image-side feature rows
     const u16* B2; const int64_t* k_rows2; int ldb2;    // text-side feature rows (k >= k_switch)
     float* out;                  // fp32 slabs [splits][M][ldo]
@@ -95,6 +99,10 @@ struct DwArgsB {
     int   dbg;                   // timing-only ablations: bit0 = no A traffic, bit1 = no F traffic
     int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit;
     int   nsplit1;               // slabs [0, nsplit1) cover k in [0, k_switch), the rest [k_switch, K): k_chunk rows each
+    const int64_t* a_rows;       // AM 1: row ids of A (never NULL: identity table for dense operands)
+    int   bcs;                   // B column-chunk stride in elements: element (k, n) of either B source at
+                                 // rid*ld + (n>>6)*bcs + (n&63); 64 = plain row-major rows
+    void* out16;                 // OM 1/2: bf16 output
     long long slab_stride;
     unsigned long long* stamps;  // diagnostics (UMLH_DBG_DW=16+bits): [blocks][8 waves][8] cycle stamps, else NULL
 };

@@ -78,6 +78,47 @@ __global__ __launch_bounds__(256) void w_shadow_kernel(const float* __restrict__
 }
 
 // --------------------------------------------------------------------------- //
+// transposed bf16 shadows of fp32 weights (2-layer head): dst(c, r) = bf16(src[r][c]) for a row-major
+// [R][Cc] source, 64x64 tiles through LDS so that both sides move whole 128/256-B segments.
+//   MODE 0: dst row-major [Cc][ldd]                      (W_proj^T: the B operand of H = X W_proj^T)
+//   MODE 1: dst chunk-major over r: [(R+63)/64][ldd][64]  (W_head^T by class chunks: the A operand of dH^T);
+//           r >= R inside the last chunk is written as 0
+// --------------------------------------------------------------------------- //
+template <int MODE>
+__global__ __launch_bounds__(256) void transpose_shadow_kernel(const float* __restrict__ src, int R, int Cc, int ldd,
+                                                               u16* __restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int rr = (t >> 6) + 4 * j, cc = t & 63;          // 64 consecutive columns per row: 256-B reads
+        const int r = r0 + rr, c = c0 + cc;
+        tile[rr][cc] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    const int cc = t >> 2, seg = (t & 3) * 16;                  // 16 consecutive r of one c: 32 B
+    const int c = c0 + cc;
+    if (c >= Cc) return;
+    u32x4 o[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned v = f2bf(tile[seg + 2 * j][cc]) | ((unsigned)f2bf(tile[seg + 2 * j + 1][cc]) << 16);
+        o[j >> 2][j & 3] = v;
+    }
+    if (MODE == 0) {
+        if (r0 + seg + 16 <= R) {                               // ldd % 8 == 0 and r0, seg multiples of 16: aligned
+            u32x4* d = reinterpret_cast<u32x4*>(dst + (size_t)c * ldd + r0 + seg);
+            d[0] = o[0]; d[1] = o[1];
+        } else {
+            for (int j = 0; j < 16 && r0 + seg + j < R; ++j) dst[(size_t)c * ldd + r0 + seg + j] = f2bf(tile[seg + j][cc]);
+        }
+    } else {
+        u32x4* d = reinterpret_cast<u32x4*>(dst + ((size_t)blockIdx.y * ldd + c) * 64 + seg);
+        d[0] = o[0]; d[1] = o[1];
+    }
+}
+
+// --------------------------------------------------------------------------- //
 // fused forward + cross entropy, bf16 operands
 // --------------------------------------------------------------------------- //
 // Streamed operand W: global -> registers (fragment-major shadow, PD k-steps deep ring per wave,
@@ -482,6 +523,7 @@ constexpr int DMASK = (int)0x80000000;
 // 512 threads = 8 waves (2 along M x 4 along N, 64x32 outputs each): two waves per SIMD, so one
 // wave's address arithmetic / LDS traffic overlaps the other's MFMAs (with 4 waves per CU every
 // phase of a chunk was serialised: 2.9k VALU instructions per wave and 22 us measured).
+template <int AM, int OM>
 __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     // two LDS buffers: chunk c+1 is written while chunk c is consumed -> ONE barrier per chunk
     __shared__ __attribute__((aligned(16))) u16 At[2][DBM * RSA];
@@ -524,16 +566,18 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     for (int q = 0; q < 2; ++q) {
         int p = tid + 512 * q;
         a_col[q] = 8 * (p & 7);
-        a_thr[q] = g.A + ((size_t)m0 + min(p >> 3, mclamp)) * 64 + a_col[q];
+        if (AM == 0) a_thr[q] = g.A + ((size_t)m0 + min(p >> 3, mclamp)) * 64 + a_col[q];
+        else a_thr[q] = g.A + (size_t)g.a_rows[m0 + min(p >> 3, mclamp)] * g.lda + a_col[q];
         f_row[q] = p >> 4;
-        f_col[q] = min(n0 + 8 * (p & 15), g.N - 8);
+        const int col = min(n0 + 8 * (p & 15), g.N - 8);
+        f_col[q] = (col >> 6) * g.bcs + (col & 63);     // row-major rows: bcs = 64 -> col
         f_colok[q] = n0 + 8 * (p & 15) < g.N;
     }
     // Branch-free loads: masked pieces read a zero page (a select on the loaded value would make the
     // compiler wait for the load right here and serialise the pipeline).
     auto gloadA = [&](Stage& sg, int c) {
         const int k0 = kb + c * DKT;
-        const size_t achunk = (size_t)(k0 >> 6) * g.lda * 64;
+        const size_t achunk = AM == 0 ? (size_t)(k0 >> 6) * g.lda * 64 : (size_t)k0;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const u16* ap = (k0 + a_col[q] < ke && !(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
@@ -623,7 +667,7 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
         const int q = pc & 1;
         const int k0 = kb + c * DKT;
         if (pc < 2) {
-            const size_t achunk = (size_t)(k0 >> 6) * g.lda * 64;
+            const size_t achunk = AM == 0 ? (size_t)(k0 >> 6) * g.lda * 64 : (size_t)k0;
             const u16* ap = (k0 + a_col[q] < ke && !(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
             sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
         } else {
@@ -671,15 +715,22 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     }
     DSTAMP(6);
 
-    float* out = g.out + (size_t)z * g.slab_stride;
     const int n = n0 + wn * 32 + l31;
     if (n < g.N) {
+        float* out = g.out + (size_t)z * g.slab_stride;
+        u16* o16 = static_cast<u16*>(g.out16);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 int m = m0 + wm * 64 + i * 32 + acc_row(e, h);
-                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][e];
+                if (m >= g.M) continue;
+                if (OM == 0) out[(size_t)m * g.ldo + n] = acc[i][e];
+                else {
+                    const u16 v = f2bf(acc[i][e]);
+                    if (OM == 1) o16[(size_t)m * g.ldo + n] = v;
+                    else o16[((size_t)(n >> 6) * g.ldo + m) * 64 + (n & 63)] = v;
+                }
             }
     }
     DSTAMP(7);
@@ -740,12 +791,26 @@ int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, 
     return (int)hipErrorInvalidValue;
 }
 
-int umlh_bf16_launch_dw(const DwArgsB* g, int splits, hipStream_t stream) {
+// mode 0: dst[c*ldd + r]; mode 1: dst[((r>>6)*ldd + c)*64 + (r&63)]  (see transpose_shadow_kernel)
+int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, void* dst, int mode, hipStream_t stream) {
+    if (R <= 0 || Cc <= 0) return 0;
+    if (ldd % 8 != 0) return (int)hipErrorInvalidValue;
+    dim3 grid((Cc + 63) / 64, (R + 63) / 64);
+    if (mode == 0) hipLaunchKernelGGL((transpose_shadow_kernel<0>), grid, dim3(256), 0, stream, src, R, Cc, ldd, (u16*)dst);
+    else hipLaunchKernelGGL((transpose_shadow_kernel<1>), grid, dim3(256), 0, stream, src, R, Cc, ldd, (u16*)dst);
+    return (int)hipGetLastError();
+}
+
+int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream) {
     if (g->M <= 0 || g->N <= 0) return 0;
     if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
+    if (g->k_switch % DKT != 0 || g->bcs < 64 || g->N % 8 != 0) return (int)hipErrorInvalidValue;
+    if ((am == 1 && !g->a_rows) || (om != 0 && (!g->out16 || splits != 1))) return (int)hipErrorInvalidValue;
     dim3 grid(((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits);
-    if (g->k_switch % DKT != 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(dw_bf16, grid, dim3(512), 0, stream, *g);
+    if (am == 0 && om == 0) hipLaunchKernelGGL((dw_bf16<0, 0>), grid, dim3(512), 0, stream, *g);
+    else if (am == 1 && om == 1) hipLaunchKernelGGL((dw_bf16<1, 1>), grid, dim3(512), 0, stream, *g);
+    else if (am == 0 && om == 2) hipLaunchKernelGGL((dw_bf16<0, 2>), grid, dim3(512), 0, stream, *g);
+    else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 
