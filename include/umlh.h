@@ -226,6 +226,47 @@ int  umlh_seq_mse_forward(const float* z, const float* w, const float* bias, con
 int  umlh_seq_mse_backward(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out,
                            int32_t B, int32_t T, int32_t Z, int32_t D, float* dz, float* dw, float* db, void* stream);
 
+/* ---- MultiBench shared encoder (MultiBench/models.py:39-127: Conv1d k=1 -> positions -> 5 x post-norm
+ * nn.TransformerEncoderLayer(z, nhead, dim_feedforward=2048, relu, dropout) under a causal + key-padding
+ * mask), forward and backward, fp32.  Token rows are m = t*B + b of a [T,B,*] activation (torch's
+ * sequence-first layout).  The host mirror (multibench/encoder.py) strings these together exactly as
+ * torch.nn.TransformerEncoderLayer.forward does; all pointers are device fp32 unless noted. ---- */
+
+/* out[m][n] = alpha * sum_k A(m,k) B(n,k).  ta = 0: A[m*lda + k], rows optionally gathered by a_rows[m];
+ * ta = 1: A[k*lda + m].  tb = 0: B[n*ldb + k];  tb = 1: B[k*ldb + n], rows optionally gathered by k_rows[k].
+ * (ta,tb) in {(0,0),(0,1),(1,1)}: y = x W^T, dx = dy W, dW = dy^T x.  fp32 MFMA (exact fp32 products). */
+int  umlh_gemm_f32(const float* A, const float* B, float* out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                   int32_t ldo, int32_t ta, int32_t tb, const int64_t* a_rows, const int64_t* k_rows, float alpha, void* stream);
+/* y[m][n] = act(y[m][n] + bias[n]) in place (bias may be NULL; relu != 0: max(.,0)) */
+int  umlh_bias_act(float* y, const float* bias, int64_t M, int32_t N, int32_t relu, void* stream);
+/* dy[i] = y[i] > 0 ? dy[i] : 0 in place */
+int  umlh_relu_backward(const float* y, float* dy, int64_t n, void* stream);
+/* x[i] = keep_i ? x[i]/(1-p) : 0 in place; keep_i is a pure function of (seed, i): the same call on the
+ * gradient is the backward pass.  p == 0: no-op. */
+int  umlh_dropout(float* x, int64_t n, float p, uint64_t seed, void* stream);
+/* y[i] += x[i]  (gradient fan-in of a residual branch) */
+int  umlh_add_inplace(float* y, const float* x, int64_t n, void* stream);
+/* out[n] = sum_m x[m][n]  (bias gradients) */
+int  umlh_colsum(const float* x, int32_t M, int32_t N, float* out, void* stream);
+/* s = x + r (r may be NULL); y = LayerNorm(s; gamma, beta, eps); mean/rstd [M] saved for the backward */
+int  umlh_add_layernorm_forward(const float* x, const float* r, const float* gamma, const float* beta, int32_t M, int32_t N,
+                                float eps, float* s, float* y, float* mean, float* rstd, void* stream);
+/* ds [M,N] (gradient of both summands of s), dgamma [N], dbeta [N] */
+int  umlh_layernorm_backward(const float* dy, const float* s, const float* gamma, const float* mean, const float* rstd,
+                             int32_t M, int32_t N, float* ds, float* dgamma, float* dbeta, void* stream);
+/* x[t,b,:] += pos[t,:]  /  dpos[t,:] = sum_b dx[t,b,:] */
+int  umlh_add_positions(float* x, const float* pos, int32_t T, int32_t B, int32_t Z, void* stream);
+int  umlh_positions_backward(const float* dx, int32_t T, int32_t B, int32_t Z, float* dpos, void* stream);
+/* scatter == 0: out[j,:] = x[idx[j],:];  scatter != 0: out[idx[j],:] = x[j,:] (out pre-zeroed, idx unique) */
+int  umlh_gather_rows(const float* x, const int64_t* idx, int32_t n, int32_t Z, float* out, int32_t scatter, void* stream);
+/* Causal multi-head self-attention with key padding over packed in-projections qkv [T,B,3Z] (torch
+ * MultiheadAttention layout), H heads; lengths int64[B] or NULL.  ctx [T,B,Z] (heads concatenated, before
+ * out_proj), lse [B,H,T] saved for the backward.  p/seed: attention-probability dropout.  T <= 128, Z/H <= 64. */
+int  umlh_attention_forward(const float* qkv, const int64_t* lengths, int32_t T, int32_t B, int32_t Z, int32_t H, float p,
+                            uint64_t seed, float* ctx, float* lse, void* stream);
+int  umlh_attention_backward(const float* qkv, const int64_t* lengths, const float* lse, const float* dctx, int32_t T, int32_t B,
+                             int32_t Z, int32_t H, float p, uint64_t seed, float* dqkv, void* stream);
+
 /* A pseudo-random permutation of 0..n-1 written as int64 (device), keyed by seed: 4-round Feistel
  * network + cycle walking, no sort.  Epoch shuffles for throughput runs; NOT the reference's
  * sampler order (that is reproduced host-side by the loader, finetune.py:370-371). */

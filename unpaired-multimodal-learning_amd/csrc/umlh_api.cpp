@@ -32,6 +32,22 @@ int umlh_launch_iota(long long* dst, long long n, hipStream_t stream);
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream);
+int umlh_enc_launch_bias_act(float* y, const float* b, long long M, int N, int relu, hipStream_t st);
+int umlh_enc_launch_relu_bwd(const float* y, float* dy, long long n, hipStream_t st);
+int umlh_enc_launch_dropout(float* x, long long n, float p, unsigned long long seed, hipStream_t st);
+int umlh_enc_launch_colsum(const float* x, int M, int N, float* out, hipStream_t st);
+int umlh_enc_launch_add_inplace(float* y, const float* x, long long n, hipStream_t st);
+int umlh_enc_launch_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, int M, int N, float eps,
+                                  float* s_out, float* y, float* mean, float* rstd, hipStream_t st);
+int umlh_enc_launch_layernorm_bwd(const float* dy, const float* s, const float* gamma, const float* mean, const float* rstd,
+                                  int M, int N, float* ds, float* dgamma, float* dbeta, hipStream_t st);
+int umlh_enc_launch_add_pos(float* x, const float* pos, int T, int B, int Z, hipStream_t st);
+int umlh_enc_launch_pos_grad(const float* dx, int T, int B, int Z, float* dpos, hipStream_t st);
+int umlh_enc_launch_gather_rows(const float* x, const int64_t* idx, int n, int Z, float* out, int scatter, hipStream_t st);
+int umlh_enc_launch_attention_fwd(const float* qkv, const int64_t* lengths, int T, int B, int Z, int H, float p,
+                                  unsigned long long seed, float* ctx, float* lse, hipStream_t st);
+int umlh_enc_launch_attention_bwd(const float* qkv, const int64_t* lengths, const float* lse, const float* dctx, int T, int B,
+                                  int Z, int H, float p, unsigned long long seed, float* dqkv, hipStream_t st);
 int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, void* dst, int mode, hipStream_t stream);
 }
 
@@ -415,6 +431,103 @@ int umlh_random_permutation(int64_t n, uint64_t seed, int64_t* out, void* stream
 int umlh_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
     if (!src || !dst || n < 0) return fail(UMLH_E_INVALID, "umlh_to_bf16: bad arguments");
     HIPCHK(umlh_launch_to_bf16(src, dst, n, (hipStream_t)stream), "to_bf16");
+    return UMLH_OK;
+}
+
+// ---- MultiBench shared encoder ops (kernels: umlh_kernels_enc.hip, GEMMs: gemm_f32) ----
+int umlh_gemm_f32(const float* A, const float* B, float* out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                  int32_t ldo, int32_t ta, int32_t tb, const int64_t* a_rows, const int64_t* k_rows, float alpha, void* stream) {
+    if (!A || !B || !out || M < 0 || N < 0 || K < 1 || (ta && a_rows) || (!tb && k_rows))
+        return fail(UMLH_E_INVALID, "umlh_gemm_f32: bad arguments");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.out = out; g.a_rows = a_rows; g.k_rows = k_rows;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = ldo;
+    g.k_chunk = K; g.slab_stride = 0; g.alpha = alpha; g.k_switch = K; g.k_valid1 = K;
+    HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, 1, (hipStream_t)stream), "gemm_f32");
+    return UMLH_OK;
+}
+
+int umlh_bias_act(float* y, const float* bias, int64_t M, int32_t N, int32_t relu, void* stream) {
+    if (!y || M < 0 || N < 1) return fail(UMLH_E_INVALID, "umlh_bias_act: bad arguments");
+    HIPCHK(umlh_enc_launch_bias_act(y, bias, M, N, relu, (hipStream_t)stream), "bias_act");
+    return UMLH_OK;
+}
+
+int umlh_relu_backward(const float* y, float* dy, int64_t n, void* stream) {
+    if (!y || !dy || n < 0) return fail(UMLH_E_INVALID, "umlh_relu_backward: bad arguments");
+    HIPCHK(umlh_enc_launch_relu_bwd(y, dy, n, (hipStream_t)stream), "relu_bwd");
+    return UMLH_OK;
+}
+
+int umlh_dropout(float* x, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!x || n < 0 || !(p >= 0.f && p < 1.f)) return fail(UMLH_E_INVALID, "umlh_dropout: bad arguments");
+    HIPCHK(umlh_enc_launch_dropout(x, n, p, seed, (hipStream_t)stream), "dropout");
+    return UMLH_OK;
+}
+
+int umlh_add_inplace(float* y, const float* x, int64_t n, void* stream) {
+    if (!y || !x || n < 0) return fail(UMLH_E_INVALID, "umlh_add_inplace: bad arguments");
+    HIPCHK(umlh_enc_launch_add_inplace(y, x, n, (hipStream_t)stream), "add_inplace");
+    return UMLH_OK;
+}
+
+int umlh_colsum(const float* x, int32_t M, int32_t N, float* out, void* stream) {
+    if (!x || !out || M < 0 || N < 1) return fail(UMLH_E_INVALID, "umlh_colsum: bad arguments");
+    HIPCHK(umlh_enc_launch_colsum(x, M, N, out, (hipStream_t)stream), "colsum");
+    return UMLH_OK;
+}
+
+int umlh_add_layernorm_forward(const float* x, const float* r, const float* gamma, const float* beta, int32_t M, int32_t N,
+                               float eps, float* s, float* y, float* mean, float* rstd, void* stream) {
+    if (!x || !gamma || !beta || !s || !y || !mean || !rstd || M < 0 || N < 1)
+        return fail(UMLH_E_INVALID, "umlh_add_layernorm_forward: bad arguments");
+    HIPCHK(umlh_enc_launch_add_layernorm(x, r, gamma, beta, M, N, eps, s, y, mean, rstd, (hipStream_t)stream), "add_layernorm");
+    return UMLH_OK;
+}
+
+int umlh_layernorm_backward(const float* dy, const float* s, const float* gamma, const float* mean, const float* rstd,
+                            int32_t M, int32_t N, float* ds, float* dgamma, float* dbeta, void* stream) {
+    if (!dy || !s || !gamma || !mean || !rstd || !ds || !dgamma || !dbeta || M < 0 || N < 1)
+        return fail(UMLH_E_INVALID, "umlh_layernorm_backward: bad arguments");
+    HIPCHK(umlh_enc_launch_layernorm_bwd(dy, s, gamma, mean, rstd, M, N, ds, dgamma, dbeta, (hipStream_t)stream), "layernorm_bwd");
+    return UMLH_OK;
+}
+
+int umlh_add_positions(float* x, const float* pos, int32_t T, int32_t B, int32_t Z, void* stream) {
+    if (!x || !pos || T < 1 || B < 1 || Z < 1) return fail(UMLH_E_INVALID, "umlh_add_positions: bad arguments");
+    HIPCHK(umlh_enc_launch_add_pos(x, pos, T, B, Z, (hipStream_t)stream), "add_pos");
+    return UMLH_OK;
+}
+
+int umlh_positions_backward(const float* dx, int32_t T, int32_t B, int32_t Z, float* dpos, void* stream) {
+    if (!dx || !dpos || T < 1 || B < 1 || Z < 1) return fail(UMLH_E_INVALID, "umlh_positions_backward: bad arguments");
+    HIPCHK(umlh_enc_launch_pos_grad(dx, T, B, Z, dpos, (hipStream_t)stream), "pos_grad");
+    return UMLH_OK;
+}
+
+int umlh_gather_rows(const float* x, const int64_t* idx, int32_t n, int32_t Z, float* out, int32_t scatter, void* stream) {
+    if (!x || !idx || !out || n < 0 || Z < 1) return fail(UMLH_E_INVALID, "umlh_gather_rows: bad arguments");
+    HIPCHK(umlh_enc_launch_gather_rows(x, idx, n, Z, out, scatter, (hipStream_t)stream), "gather_rows");
+    return UMLH_OK;
+}
+
+int umlh_attention_forward(const float* qkv, const int64_t* lengths, int32_t T, int32_t B, int32_t Z, int32_t H, float p,
+                           uint64_t seed, float* ctx, float* lse, void* stream) {
+    if (!qkv || !ctx || !lse || B < 1 || !(p >= 0.f && p < 1.f)) return fail(UMLH_E_INVALID, "umlh_attention_forward: bad arguments");
+    if (T < 1 || T > 128 || H < 1 || Z % H != 0 || Z / H > 64)
+        return fail(UMLH_E_INVALID, "umlh_attention_forward: T=%d Z=%d H=%d outside the kernel's envelope (T <= 128, Z/H <= 64)", T, Z, H);
+    HIPCHK(umlh_enc_launch_attention_fwd(qkv, lengths, T, B, Z, H, p, seed, ctx, lse, (hipStream_t)stream), "attention_fwd");
+    return UMLH_OK;
+}
+
+int umlh_attention_backward(const float* qkv, const int64_t* lengths, const float* lse, const float* dctx, int32_t T, int32_t B,
+                            int32_t Z, int32_t H, float p, uint64_t seed, float* dqkv, void* stream) {
+    if (!qkv || !lse || !dctx || !dqkv || B < 1 || !(p >= 0.f && p < 1.f))
+        return fail(UMLH_E_INVALID, "umlh_attention_backward: bad arguments");
+    if (T < 1 || T > 128 || H < 1 || Z % H != 0 || Z / H > 64)
+        return fail(UMLH_E_INVALID, "umlh_attention_backward: T=%d Z=%d H=%d outside the kernel's envelope", T, Z, H);
+    HIPCHK(umlh_enc_launch_attention_bwd(qkv, lengths, lse, dctx, T, B, Z, H, p, seed, dqkv, (hipStream_t)stream), "attention_bwd");
     return UMLH_OK;
 }
 

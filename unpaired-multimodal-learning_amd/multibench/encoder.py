@@ -1,0 +1,239 @@
+"""The MultiBench shared encoder on HIP kernels: forward AND backward of
+``Conv1d(k=1, no bias) -> positions -> N x nn.TransformerEncoderLayer (post-norm, relu, dropout) -> last
+valid token`` (reference MultiBench/models.py:39-127) as one ``torch.autograd.Function`` over the C ABI of
+``include/umlh.h`` (umlh_gemm_f32, umlh_attention_*, umlh_add_layernorm_*, ...).  torch supplies device
+memory and the autograd plumbing around the function; none of the arithmetic.
+
+Activations are token-row matrices ``[T*B, *]`` with row ``m = t*B + b`` (torch's sequence-first layout),
+so the math is line for line that of ``torch.nn.TransformerEncoderLayer.forward`` (norm_first=False):
+
+    x = norm1(x + dropout1(self_attn(x)));  x = norm2(x + dropout2(linear2(dropout(relu(linear1(x))))))
+
+Dropout masks are counter-based (a pure function of a per-call seed and the element index), so the
+backward regenerates them instead of storing them; train-mode trajectories are therefore not
+bit-comparable with torch's Philox masks (the reference's train mode is unpinnable anyway: SURVEY 8(a14))
+while eval mode is compared with torch.nn to 1e-5.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+import umlh
+from umlh._lib import check
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def gemm(a, b, m, n, k, lda, ldb, ta, tb, a_rows=None, k_rows=None, alpha=1.0):
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    check(umlh.load_library().umlh_gemm_f32(_p(a), _p(b), _p(out), m, n, k, lda, ldb, n, ta, tb, _p(a_rows), _p(k_rows),
+                                            float(alpha), _st(a.device)), "umlh_gemm_f32")
+    return out
+
+
+def linear_forward(x, w, b, relu=False, a_rows=None, rows=None):
+    """y = act(x w^T + b); x [M,K] (rows optionally gathered by a_rows -> `rows` output rows), w [N,K]."""
+    m = x.shape[0] if rows is None else rows
+    y = gemm(x, w, m, w.shape[0], w.shape[1], x.shape[1], w.shape[1], 0, 0, a_rows=a_rows)
+    if b is not None or relu:
+        check(umlh.load_library().umlh_bias_act(_p(y), _p(b), m, w.shape[0], int(relu), _st(x.device)), "umlh_bias_act")
+    return y
+
+
+def linear_backward(x, w, dy, need_dx=True, has_bias=True, x_rows=None, dx_rows=None, n_dx_rows=None):
+    """(dx, dw, db) of y = x w^T + b.  x_rows: y row m used x row x_rows[m]; dx_rows: dx row r takes dy row dx_rows[r]."""
+    lib, st = umlh.load_library(), _st(dy.device)
+    m, n, k = dy.shape[0], w.shape[0], w.shape[1]
+    dw = gemm(dy, x, n, k, m, n, k, 1, 1, k_rows=x_rows)                       # dw[n][k] = sum_m dy[m][n] x[m][k]
+    db = None
+    if has_bias:
+        db = torch.empty(n, dtype=torch.float32, device=dy.device)
+        check(lib.umlh_colsum(_p(dy), m, n, _p(db), st), "umlh_colsum")
+    dx = None
+    if need_dx:
+        rows = m if n_dx_rows is None else n_dx_rows
+        dx = gemm(dy, w, rows, k, n, n, k, 0, 1, a_rows=dx_rows)               # dx[m][k] = sum_n dy[m][n] w[n][k]
+    return dx, dw, db
+
+
+def _dropout_(x, p, seed):
+    if p > 0.0:
+        check(umlh.load_library().umlh_dropout(_p(x), x.numel(), float(p), C.c_uint64(seed & (2 ** 64 - 1)), _st(x.device)), "umlh_dropout")
+    return x
+
+
+def _add_(y, x):
+    check(umlh.load_library().umlh_add_inplace(_p(y), _p(x), y.numel(), _st(y.device)), "umlh_add_inplace")
+    return y
+
+
+def _add_ln(x, r, gamma, beta, eps):
+    m, n = x.shape
+    s, y = torch.empty_like(x), torch.empty_like(x)
+    mean = torch.empty(m, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(umlh.load_library().umlh_add_layernorm_forward(_p(x), _p(r), _p(gamma), _p(beta), m, n, float(eps), _p(s), _p(y),
+                                                         _p(mean), _p(rstd), _st(x.device)), "umlh_add_layernorm_forward")
+    return s, y, mean, rstd
+
+
+def _ln_bwd(dy, s, gamma, mean, rstd):
+    m, n = dy.shape
+    ds = torch.empty_like(dy)
+    dg = torch.empty(n, dtype=torch.float32, device=dy.device)
+    db = torch.empty_like(dg)
+    check(umlh.load_library().umlh_layernorm_backward(_p(dy), _p(s), _p(gamma), _p(mean), _p(rstd), m, n, _p(ds), _p(dg), _p(db),
+                                                      _st(dy.device)), "umlh_layernorm_backward")
+    return ds, dg, db
+
+
+N_LAYER_PARAMS = 12   # in_w, in_b, out_w, out_b, w1, b1, w2, b2, g1, be1, g2, be2
+
+
+class EncoderFn(torch.autograd.Function):
+    """x [B,T,F] -> conv -> (+pos) -> layers -> output rows.  ``cfg`` = dict(T, B, H, p, eps, seed, out_mode)
+    with out_mode 'last_len' | 'last' | 'all'; ``params`` = conv_w | None, pos [T,Z] | None, then 12 tensors per layer."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, cfg, conv_w, pos, *layer_params):
+        lib = umlh.load_library()
+        dev = x.device
+        B, T, F = x.shape
+        H, p, eps, seed = cfg["H"], cfg["p"], cfg["eps"], cfg["seed"]
+        st = _st(dev)
+        x2d = _f32(x).reshape(B * T, F)
+        lens = None if lengths is None else lengths.to(device=dev, dtype=torch.int64).contiguous()
+        ar_b = torch.arange(B, device=dev, dtype=torch.int64)
+        ar_t = torch.arange(T, device=dev, dtype=torch.int64)
+        rows_tb = (ar_b.unsqueeze(0) * T + ar_t.unsqueeze(1)).reshape(-1).contiguous()      # token row m=(t,b) -> source row b*T+t
+        rows_bt = (ar_t.unsqueeze(0) * B + ar_b.unsqueeze(1)).reshape(-1).contiguous()      # source row (b,t) -> token row t*B+b
+        M = T * B
+        if conv_w is not None:
+            cw = _f32(conv_w).reshape(conv_w.shape[0], -1)
+            h = linear_forward(x2d, cw, None, a_rows=rows_tb, rows=M)                        # [M, Z]
+        else:
+            cw = None
+            h = torch.empty(M, F, dtype=torch.float32, device=dev)
+            check(lib.umlh_gather_rows(_p(x2d), _p(rows_tb), M, F, _p(h), 0, st), "umlh_gather_rows")
+        Z = h.shape[1]
+        if pos is not None:
+            check(lib.umlh_add_positions(_p(h), _p(_f32(pos)), T, B, Z, st), "umlh_add_positions")
+        saved = []
+        n_layers = len(layer_params) // N_LAYER_PARAMS
+        lp = [_f32(t) for t in layer_params]
+        for li in range(n_layers):
+            in_w, in_b, out_w, out_b, w1, b1, w2, b2, g1, be1, g2, be2 = lp[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS]
+            sd = seed + 7919 * li
+            qkv = linear_forward(h, in_w, in_b)                                              # [M, 3Z]
+            att = torch.empty(M, Z, dtype=torch.float32, device=dev)
+            lse = torch.empty(B * H * T, dtype=torch.float32, device=dev)
+            check(lib.umlh_attention_forward(_p(qkv), _p(lens), T, B, Z, H, float(p), C.c_uint64(sd), _p(att), _p(lse), st),
+                  "umlh_attention_forward")
+            a = _dropout_(linear_forward(att, out_w, out_b), p, sd + 1)
+            s1, x1, mean1, rstd1 = _add_ln(h, a, g1, be1, eps)
+            hid = _dropout_(linear_forward(x1, w1, b1, relu=True), p, sd + 2)               # [M, dff]
+            f = _dropout_(linear_forward(hid, w2, b2), p, sd + 3)
+            s2, x2, mean2, rstd2 = _add_ln(x1, f, g2, be2, eps)
+            saved.append((h, qkv, lse, att, s1, mean1, rstd1, x1, hid, s2, mean2, rstd2))
+            h = x2
+        mode = cfg["out_mode"]
+        if mode == "all":
+            idx, n_out = rows_bt, M
+        elif mode == "last_len":
+            idx, n_out = ((lens - 1) * B + ar_b).contiguous(), B
+        else:
+            idx, n_out = ((T - 1) * B + ar_b).contiguous(), B
+        out = torch.empty(n_out, Z, dtype=torch.float32, device=dev)
+        check(lib.umlh_gather_rows(_p(h), _p(idx), n_out, Z, _p(out), 0, st), "umlh_gather_rows")
+        ctx.cfg, ctx.dims = cfg, (B, T, F, Z, M, n_layers)
+        ctx.aux = (x2d, lens, rows_tb, rows_bt, idx, cw, pos is not None, lp, saved)
+        ctx.need_dx = x.requires_grad
+        return out.reshape(B, T, Z) if mode == "all" else out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = umlh.load_library()
+        cfg = ctx.cfg
+        B, T, F, Z, M, n_layers = ctx.dims
+        x2d, lens, rows_tb, rows_bt, idx, cw, has_pos, lp, saved = ctx.aux
+        H, p, seed = cfg["H"], cfg["p"], cfg["seed"]
+        dev = g_out.device
+        st = _st(dev)
+        g = _f32(g_out).reshape(-1, Z)
+        dh = torch.zeros(M, Z, dtype=torch.float32, device=dev)
+        check(lib.umlh_gather_rows(_p(g), _p(idx), g.shape[0], Z, _p(dh), 1, st), "umlh_gather_rows(scatter)")
+        grads = [None] * (n_layers * N_LAYER_PARAMS)
+        for li in reversed(range(n_layers)):
+            in_w, in_b, out_w, out_b, w1, b1, w2, b2, g1, be1, g2, be2 = lp[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS]
+            h_in, qkv, lse, att, s1, mean1, rstd1, x1, hid, s2, mean2, rstd2 = saved[li]
+            sd = seed + 7919 * li
+            ds2, dg2, dbe2 = _ln_bwd(dh, s2, g2, mean2, rstd2)                   # s2 = x1 + f
+            df = _dropout_(ds2.clone(), p, sd + 3)
+            dhid, dw2, db2 = linear_backward(hid, w2, df)
+            _dropout_(dhid, p, sd + 2)
+            check(lib.umlh_relu_backward(_p(hid), _p(dhid), dhid.numel(), st), "umlh_relu_backward")
+            dx1, dw1, db1 = linear_backward(x1, w1, dhid)
+            _add_(dx1, ds2)                                                      # residual fan-in at x1
+            ds1, dg1, dbe1 = _ln_bwd(dx1, s1, g1, mean1, rstd1)                  # s1 = h_in + a
+            da = _dropout_(ds1.clone(), p, sd + 1)
+            datt, dow, dob = linear_backward(att, out_w, da)
+            dqkv = torch.empty(M, 3 * Z, dtype=torch.float32, device=dev)
+            check(lib.umlh_attention_backward(_p(qkv), _p(lens), _p(lse), _p(datt), T, B, Z, H, float(p), C.c_uint64(sd), _p(dqkv), st),
+                  "umlh_attention_backward")
+            dxin, dinw, dinb = linear_backward(h_in, in_w, dqkv)
+            dh = _add_(dxin, ds1)                                                # residual fan-in at the layer input
+            grads[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS] = [dinw, dinb, dow, dob, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2]
+        dpos = None
+        if has_pos:
+            dpos = torch.empty(T, Z, dtype=torch.float32, device=dev)
+            check(lib.umlh_positions_backward(_p(dh), T, B, Z, _p(dpos), st), "umlh_positions_backward")
+        dconv = dx = None
+        if cw is not None:
+            dx, dconv, _ = linear_backward(x2d, cw, dh, need_dx=ctx.need_dx, has_bias=False, x_rows=rows_tb, dx_rows=rows_bt,
+                                           n_dx_rows=B * T)
+            dconv = dconv.reshape(cw.shape[0], cw.shape[1], 1)
+        elif ctx.need_dx:
+            dx = torch.empty(B * T, F, dtype=torch.float32, device=dev)
+            check(lib.umlh_gather_rows(_p(dh), _p(rows_bt), B * T, F, _p(dx), 0, st), "umlh_gather_rows")
+        if dx is not None:
+            dx = dx.reshape(B, T, F)
+        return (dx, None, None, dconv, dpos, *grads)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x w^T + b over the trailing dimension (the per-modality in/out projections, models.py:7-35)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = _f32(x).reshape(-1, x.shape[-1])
+        w2, b2 = _f32(w), (None if b is None else _f32(b))
+        y = linear_forward(x2, w2, b2)
+        ctx.save_for_backward(x2, w2)
+        ctx.has_bias, ctx.shape, ctx.need_dx = b is not None, x.shape, x.requires_grad
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w2 = ctx.saved_tensors
+        dy = _f32(gy).reshape(-1, w2.shape[0])
+        dx, dw, db = linear_backward(x2, w2, dy, need_dx=ctx.need_dx, has_bias=ctx.has_bias)
+        return (None if dx is None else dx.reshape(ctx.shape)), dw, db
+
+
+def layer_params(layer):
+    """The 12 tensors of one nn.TransformerEncoderLayer in EncoderFn's order."""
+    a = layer.self_attn
+    return [a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, layer.linear1.weight, layer.linear1.bias,
+            layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias]

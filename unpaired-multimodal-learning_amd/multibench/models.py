@@ -22,12 +22,14 @@ class Linear(nn.Module):
             self.fc.bias.data.fill_(0.0)
 
     def forward(self, x):
-        return self.fc(x)
+        from .encoder import LinearFn
+        return LinearFn.apply(x, self.fc.weight, self.fc.bias)
 
 
 class Transformer(nn.Module):
     """Shared encoder: 1x1 conv (no bias) -> optional positions -> causal TransformerEncoder with
-    key-padding mask (models.py:39-127).  Third-party torch.nn arithmetic, kept on PyTorch-ROCm."""
+    key-padding mask (models.py:39-127).  The nn modules are parameter containers (same init, same
+    ``state_dict`` keys as the reference); the arithmetic runs on the HIP kernels of encoder.py."""
 
     def __init__(self, n_features, dim, nhead=5, num_layers=5, conv1d=True, out_last=True, pos_embd=False,
                  pos_learnable=False, max_len=128):
@@ -49,27 +51,27 @@ class Transformer(nn.Module):
                 self.register_buffer("pos_table", table)
 
     def forward(self, x, lengths=None):
+        """models.py:75-127 on the HIP encoder (multibench/encoder.py): conv1d -> positions -> causal
+        transformer layers under the key-padding mask -> last valid token / all tokens."""
+        from .encoder import EncoderFn, layer_params
         if type(x) is list:
             x = x[0]
-        batch, seq_len, _ = x.shape
-        pad = None
-        if lengths is not None:
-            pad = torch.arange(seq_len, device=x.device).expand(batch, seq_len) >= lengths.unsqueeze(1)
-        x = self.conv(x.permute(0, 2, 1)).permute(2, 0, 1) if self.conv1d else x.permute(1, 0, 2)   # (T, B, D)
+        if not x.is_cuda:
+            raise RuntimeError("multibench.Transformer runs on the HIP kernels only: move the model and inputs to the GPU")
+        if self.pos_embd and x.size(1) > self.max_len:
+            x = x[:, :self.max_len]                                           # models.py:104-106
+        T = x.size(1)
+        pos = None
         if self.pos_embd:
-            if x.size(0) > self.max_len:
-                x = x[:self.max_len]
-            idx = torch.arange(x.size(0), device=x.device)
-            pos = self.pos_embedding(idx) if self.pos_learnable else self.pos_table[idx]
-            x = x + pos.unsqueeze(1)
-        causal = torch.nn.Transformer.generate_square_subsequent_mask(x.size(0), device=x.device)
-        x = self.transformer(x, mask=causal, src_key_padding_mask=pad, is_causal=True)
-        if self.out_last:
-            if lengths is not None:
-                x = x.permute(1, 0, 2)
-                return x[torch.arange(batch, device=x.device), lengths - 1, :]
-            return x[-1]
-        return x.permute(1, 0, 2)
+            pos = self.pos_embedding.weight[:T] if self.pos_learnable else self.pos_table[:T]
+        layers = self.transformer.layers
+        l0 = layers[0]
+        p = float(l0.dropout.p) if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
+        cfg = {"H": l0.self_attn.num_heads, "p": p, "eps": float(l0.norm1.eps), "seed": seed,
+               "out_mode": ("last_len" if lengths is not None else "last") if self.out_last else "all"}
+        params = [t for layer in layers for t in layer_params(layer)]
+        return EncoderFn.apply(x, lengths, cfg, self.conv.weight if self.conv1d else None, pos, *params)
 
 
 class MSE(nn.Module):

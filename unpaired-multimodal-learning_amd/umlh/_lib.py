@@ -20,13 +20,16 @@ PREC_IDS = {"fp32": 0, "bf16": 1}
 N_CORE_SCALARS = 8
 N_SCALARS = 12
 
-SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_seq.hip", "umlh_api.cpp"]
+SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_seq.hip", "umlh_kernels_enc.hip", "umlh_api.cpp"]
 EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
            "umlh_train_steps", "umlh_seq_mse_forward", "umlh_seq_mse_backward",
-           "umlh_random_permutation", "umlh_debug_buffer"]
+           "umlh_random_permutation", "umlh_debug_buffer",
+           "umlh_gemm_f32", "umlh_add_inplace", "umlh_bias_act", "umlh_relu_backward", "umlh_dropout", "umlh_colsum",
+           "umlh_add_layernorm_forward", "umlh_layernorm_backward", "umlh_add_positions", "umlh_positions_backward",
+           "umlh_gather_rows", "umlh_attention_forward", "umlh_attention_backward"]
 
 
 class UmlhError(RuntimeError):
@@ -108,6 +111,20 @@ def load_library():
     lib.umlh_destroy.argtypes = [vp]
     lib.umlh_bind.argtypes = [vp, C.POINTER(Buffers)]
     lib.umlh_enable_diagnostics.argtypes = [vp, C.c_int32]
+    i32, f32 = C.c_int32, C.c_float
+    lib.umlh_gemm_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp]
+    lib.umlh_bias_act.argtypes = [vp, vp, i64, i32, i32, vp]
+    lib.umlh_add_inplace.argtypes = [vp, vp, i64, vp]
+    lib.umlh_relu_backward.argtypes = [vp, vp, i64, vp]
+    lib.umlh_dropout.argtypes = [vp, i64, f32, u64, vp]
+    lib.umlh_colsum.argtypes = [vp, i32, i32, vp, vp]
+    lib.umlh_add_layernorm_forward.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]
+    lib.umlh_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.umlh_add_positions.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.umlh_positions_backward.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.umlh_gather_rows.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    lib.umlh_attention_forward.argtypes = [vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, vp]
+    lib.umlh_attention_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp]
     lib.umlh_zero_shot_init.argtypes = [vp, vp, vp, i64, vp]
     lib.umlh_logits.argtypes = [vp, C.POINTER(Batch), C.c_int, vp, vp]
     lib.umlh_train_step.argtypes = [vp, C.POINTER(Batch), C.POINTER(Batch), C.POINTER(Hyper), vp, vp]
