@@ -54,15 +54,21 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y,
 }
 
 // out[n] = sum_m x[m][n]      one block per 64 columns, 4 row groups, fixed summation order
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int N, float* __restrict__ out) {
-    __shared__ float sh[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+constexpr int CG = 16;     // row groups of the column reductions (1024 threads: these are latency-bound row walks)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int M, int N, float* __restrict__ out) {
+    __shared__ float sh[CG][64];
+    const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6;
     float s = 0.f;
     if (c < N)
-        for (int m = g; m < M; m += 4) s += x[(size_t)m * N + c];
-    sh[g][threadIdx.x & 63] = s;
+        for (int m = g; m < M; m += CG) s += x[(size_t)m * N + c];
+    sh[g][l] = s;
     __syncthreads();
-    if (g == 0 && c < N) out[c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (g == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CG; ++k) t += sh[k][l];
+        out[c] = t;
+    }
 }
 
 // s = x + r (r may be NULL); y = LayerNorm(s) * gamma + beta; one wave per row
@@ -115,15 +121,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const float* __
 }
 
 // dgamma[n] = sum_m dy*xhat, dbeta[n] = sum_m dy    (column kernel, fixed order)
-__global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+__global__ __launch_bounds__(1024) void layernorm_bwd_cols_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  int M, int N, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta) {
-    __shared__ float sh[2][4][64];
+    __shared__ float sh[2][CG][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, l = threadIdx.x & 63;
     float a = 0.f, b = 0.f;
     if (c < N)
-        for (int m = g; m < M; m += 4) {
+        for (int m = g; m < M; m += CG) {
             float d = dy[(size_t)m * N + c];
             a += d * (s[(size_t)m * N + c] - mean[m]) * rstd[m];
             b += d;
@@ -131,8 +137,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __
     sh[0][g][l] = a; sh[1][g][l] = b;
     __syncthreads();
     if (g == 0 && c < N) {
-        dgamma[c] = sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l];
-        dbeta[c] = sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l];
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int k = 0; k < CG; ++k) { ta += sh[0][k][l]; tb += sh[1][k][l]; }
+        dgamma[c] = ta;
+        dbeta[c] = tb;
     }
 }
 
@@ -165,141 +174,192 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 // --------------------------------------------------------------------------- //
-// causal multi-head self-attention with key padding, one workgroup per (batch, head), one thread per
-// query row.  qkv rows are token rows m = t*B + b of [q | k | v] (3Z floats), head h = columns
-// h*dh .. h*dh+dh of each third (torch.nn.MultiheadAttention's packed in_proj layout).
-// K and V of the head sit in LDS; every thread streams over its keys with an online softmax.
-// Attention-probability dropout uses the counter mask at element ((b*H + h)*T + t)*T + j.
+// causal multi-head self-attention with key padding, one workgroup (4 waves) per (batch, head).
+// qkv rows are token rows m = t*B + b of [q | k | v] (3Z floats), head h = columns h*dh .. h*dh+dh of
+// each third (torch.nn.MultiheadAttention's packed in_proj layout).  Q, K, V (and dO) of the head sit in
+// LDS with an odd row stride.  A WAVE owns a query row: lanes are keys for the scores / softmax (wave
+// reductions), then lanes are head-dim columns for the P.V product (probabilities broadcast from LDS).
+// The backward mirrors it: phase 1 a wave per query (D_t, dS, dq), phase 2 a wave per key (dk, dv) --
+// every sum has a fixed order, no atomics.  Attention-probability dropout uses the counter mask at element
+// ((b*H + h)*T + t)*T + j.
 // --------------------------------------------------------------------------- //
 constexpr int ADH = 64;    // max head dim
+constexpr int ATM = 128;   // max sequence length
+constexpr int AW = 4;      // waves per workgroup
 
-__global__ __launch_bounds__(128) void attention_fwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
                                                             int T, int B, int Z, int H, unsigned thresh, float inv_keep,
                                                             unsigned long long seed, float* __restrict__ ctx,
                                                             float* __restrict__ lse) {
     extern __shared__ float sm[];
-    const int dh = Z / H, b = blockIdx.x / H, h = blockIdx.x % H, t = threadIdx.x;
-    float* Ks = sm;
-    float* Vs = sm + (size_t)T * dh;
-    for (int i = threadIdx.x; i < T * dh; i += blockDim.x) {
+    const int dh = Z / H, rs = dh | 1, b = blockIdx.x / H, h = blockIdx.x % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* Qs = sm;
+    float* Ks = Qs + (size_t)T * rs;
+    float* Vs = Ks + (size_t)T * rs;
+    float* Ps = Vs + (size_t)T * rs;                   // [AW][T]
+    const float scale = rsqrtf((float)dh);
+    for (int i = threadIdx.x; i < T * dh; i += 256) {
         int j = i / dh, d = i % dh;
         const float* row = qkv + ((size_t)j * B + b) * 3 * Z + h * dh + d;
-        Ks[i] = row[Z];
-        Vs[i] = row[2 * Z];
+        Qs[j * rs + d] = row[0] * scale;
+        Ks[j * rs + d] = row[Z];
+        Vs[j * rs + d] = row[2 * Z];
     }
     __syncthreads();
-    if (t >= T) return;
     const int len = lengths ? (int)lengths[b] : T;
-    const int jmax = min(t + 1, len);                 // keys j <= t and j < len
-    const float scale = rsqrtf((float)dh);
-    float q[ADH], o[ADH];
-    const float* qrow = qkv + ((size_t)t * B + b) * 3 * Z + h * dh;
+    float* P = Ps + wave * T;
+    const unsigned long long hb = ((unsigned long long)b * H + h) * T;
+    for (int t = wave; t < T; t += AW) {
+        const int jmax = min(t + 1, len);             // keys j <= t and j < len
+        float sc[2];
 #pragma unroll
-    for (int d = 0; d < ADH; ++d) { q[d] = d < dh ? qrow[d] * scale : 0.f; o[d] = 0.f; }
-    float mx = -__builtin_huge_valf(), l = 0.f;
-    const unsigned long long mbase = (((unsigned long long)b * H + h) * T + t) * T;
-    for (int j = 0; j < jmax; ++j) {
-        float sc = 0.f;
+        for (int ps = 0; ps < 2; ++ps) {
+            const int j = ps * 64 + lane;
+            float a = -__builtin_huge_valf();
+            if (j < jmax) {
+                a = 0.f;
+                for (int d = 0; d < dh; ++d) a = __builtin_fmaf(Qs[t * rs + d], Ks[j * rs + d], a);
+            }
+            sc[ps] = a;
+        }
+        const float mx = wave_max(fmaxf(sc[0], sc[1]));
+        float l = 0.f;
 #pragma unroll
-        for (int d = 0; d < ADH; ++d) if (d < dh) sc = __builtin_fmaf(q[d], Ks[j * dh + d], sc);
-        const float nm = fmaxf(mx, sc);
-        const float corr = __expf(mx - nm), p = __expf(sc - nm);
-        l = l * corr + p;
-        const float pd = (thresh == 0 || keep_elem(seed, mbase + j, thresh)) ? p * inv_keep : 0.f;
-#pragma unroll
-        for (int d = 0; d < ADH; ++d) if (d < dh) o[d] = o[d] * corr + pd * Vs[j * dh + d];
-        mx = nm;
+        for (int ps = 0; ps < 2; ++ps) {
+            const int j = ps * 64 + lane;
+            const float pj = j < jmax ? __expf(sc[ps] - mx) : 0.f;
+            l += pj;
+            if (j < T) P[j] = (thresh == 0 || keep_elem(seed, (hb + t) * T + j, thresh)) ? pj * inv_keep : 0.f;
+        }
+        l = wave_sum(l);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < dh) {
+            float o = 0.f;
+            for (int j = 0; j < jmax; ++j) o = __builtin_fmaf(P[j], Vs[j * rs + lane], o);
+            ctx[((size_t)t * B + b) * Z + h * dh + lane] = jmax > 0 ? o / l : 0.f;
+        }
+        if (lane == 0) lse[hb + t] = jmax > 0 ? mx + __logf(l) : 0.f;
+        __builtin_amdgcn_wave_barrier();               // P is reused by this wave's next query
     }
-    // jmax >= 1 whenever len >= 1 (key 0 is always visible)
-    const float inv_l = jmax > 0 ? 1.f / l : 0.f;
-    float* orow = ctx + ((size_t)t * B + b) * Z + h * dh;
-#pragma unroll
-    for (int d = 0; d < ADH; ++d) if (d < dh) orow[d] = o[d] * inv_l;
-    lse[((size_t)b * H + h) * T + t] = jmax > 0 ? mx + __logf(l) : 0.f;
 }
 
-// backward: phase 1 (thread = query t): D_t = sum_j p_tj dP_tj, dq_t = scale * sum_j dS_tj k_j;
-// phase 2 (thread = key j): dk_j = scale * sum_{t>=j} dS_tj q_t, dv_j = sum_{t>=j} pdrop_tj dO_t,
-// with p_tj = exp(s_tj - lse_t), dP_tj = (dO_t . v_j) * mask/(1-p), dS_tj = p_tj (dP_tj - D_t).
-__global__ __launch_bounds__(128) void attention_bwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
+// backward: p_tj = exp(s_tj - lse_t), dP_tj = (dO_t . v_j) * mask/(1-p), D_t = sum_j p_tj dP_tj,
+// dS_tj = p_tj (dP_tj - D_t) * scale;  dq_t = sum_j dS_tj k_j, dk_j = sum_t dS_tj q_t, dv_j = sum_t pdrop_tj dO_t
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
                                                             const float* __restrict__ lse, const float* __restrict__ dctx,
                                                             int T, int B, int Z, int H, unsigned thresh, float inv_keep,
                                                             unsigned long long seed, float* __restrict__ dqkv) {
     extern __shared__ float sm[];
-    const int dh = Z / H, b = blockIdx.x / H, h = blockIdx.x % H, t = threadIdx.x;
+    const int dh = Z / H, rs = dh | 1, b = blockIdx.x / H, h = blockIdx.x % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* Qs = sm;
-    float* Ks = Qs + (size_t)T * dh;
-    float* Vs = Ks + (size_t)T * dh;
-    float* Gs = Vs + (size_t)T * dh;                   // dO
-    float* Ds = Gs + (size_t)T * dh;                   // [T] D_t
+    float* Ks = Qs + (size_t)T * rs;
+    float* Vs = Ks + (size_t)T * rs;
+    float* Gs = Vs + (size_t)T * rs;                   // dO
+    float* Ds = Gs + (size_t)T * rs;                   // [T] D_t
     float* Ls = Ds + T;                                // [T] lse_t
-    for (int i = threadIdx.x; i < T * dh; i += blockDim.x) {
+    float* S1 = Ls + T + wave * 2 * T;                 // per wave: [T] dS, [T] dropped probabilities
+    float* S2 = S1 + T;
+    for (int i = threadIdx.x; i < T * dh; i += 256) {
         int j = i / dh, d = i % dh;
         const float* row = qkv + ((size_t)j * B + b) * 3 * Z + h * dh + d;
-        Qs[i] = row[0]; Ks[i] = row[Z]; Vs[i] = row[2 * Z];
-        Gs[i] = dctx[((size_t)j * B + b) * Z + h * dh + d];
+        Qs[j * rs + d] = row[0]; Ks[j * rs + d] = row[Z]; Vs[j * rs + d] = row[2 * Z];
+        Gs[j * rs + d] = dctx[((size_t)j * B + b) * Z + h * dh + d];
     }
-    if (t < T) Ls[t] = lse[((size_t)b * H + h) * T + t];
+    const unsigned long long hb = ((unsigned long long)b * H + h) * T;
+    for (int i = threadIdx.x; i < T; i += 256) Ls[i] = lse[hb + i];
     __syncthreads();
     const int len = lengths ? (int)lengths[b] : T;
     const float scale = rsqrtf((float)dh);
-    const unsigned long long hb = ((unsigned long long)b * H + h) * T;
-    if (t < T) {
+    // ---- phase 1: a wave per query t ----
+    for (int t = wave; t < T; t += AW) {
         const int jmax = min(t + 1, len);
-        float q[ADH], g[ADH], dq[ADH];
-#pragma unroll
-        for (int d = 0; d < ADH; ++d) { q[d] = d < dh ? Qs[t * dh + d] : 0.f; g[d] = d < dh ? Gs[t * dh + d] : 0.f; dq[d] = 0.f; }
         const float lt = Ls[t];
-        float D = 0.f;
-        for (int j = 0; j < jmax; ++j) {
-            float sc = 0.f, dp = 0.f;
+        float pj[2], dp[2], D = 0.f;
 #pragma unroll
-            for (int d = 0; d < ADH; ++d) if (d < dh) { sc = __builtin_fmaf(q[d], Ks[j * dh + d], sc); dp = __builtin_fmaf(g[d], Vs[j * dh + d], dp); }
-            const float p = __expf(sc * scale - lt);
-            if (thresh != 0) dp = keep_elem(seed, (hb + t) * T + j, thresh) ? dp * inv_keep : 0.f;
-            D = __builtin_fmaf(p, dp, D);
-        }
-        Ds[t] = D;
-        for (int j = 0; j < jmax; ++j) {
-            float sc = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < ADH; ++d) if (d < dh) { sc = __builtin_fmaf(q[d], Ks[j * dh + d], sc); dp = __builtin_fmaf(g[d], Vs[j * dh + d], dp); }
-            const float p = __expf(sc * scale - lt);
-            if (thresh != 0) dp = keep_elem(seed, (hb + t) * T + j, thresh) ? dp * inv_keep : 0.f;
-            const float dS = p * (dp - D) * scale;
-#pragma unroll
-            for (int d = 0; d < ADH; ++d) if (d < dh) dq[d] = __builtin_fmaf(dS, Ks[j * dh + d], dq[d]);
-        }
-        float* dqrow = dqkv + ((size_t)t * B + b) * 3 * Z + h * dh;
-#pragma unroll
-        for (int d = 0; d < ADH; ++d) if (d < dh) dqrow[d] = dq[d];
-    }
-    __syncthreads();
-    if (t < T) {
-        const int j = t;                                // this thread's key
-        float k[ADH], v[ADH], dk[ADH], dv[ADH];
-#pragma unroll
-        for (int d = 0; d < ADH; ++d) { k[d] = d < dh ? Ks[j * dh + d] : 0.f; v[d] = d < dh ? Vs[j * dh + d] : 0.f; dk[d] = 0.f; dv[d] = 0.f; }
-        if (j < len) {
-            for (int tq = j; tq < T; ++tq) {            // queries that see key j
-                float sc = 0.f, dp = 0.f;
-#pragma unroll
-                for (int d = 0; d < ADH; ++d) if (d < dh) { sc = __builtin_fmaf(Qs[tq * dh + d], k[d], sc); dp = __builtin_fmaf(Gs[tq * dh + d], v[d], dp); }
-                const float p = __expf(sc * scale - Ls[tq]);
-                float pd = p;
-                if (thresh != 0) {
-                    const bool kp = keep_elem(seed, (hb + tq) * T + j, thresh);
-                    dp = kp ? dp * inv_keep : 0.f;
-                    pd = kp ? p * inv_keep : 0.f;
+        for (int ps = 0; ps < 2; ++ps) {
+            const int j = ps * 64 + lane;
+            pj[ps] = dp[ps] = 0.f;
+            if (j < jmax) {
+                float a = 0.f, c = 0.f;
+                for (int d = 0; d < dh; ++d) {
+                    a = __builtin_fmaf(Qs[t * rs + d], Ks[j * rs + d], a);
+                    c = __builtin_fmaf(Gs[t * rs + d], Vs[j * rs + d], c);
                 }
-                const float dS = p * (dp - Ds[tq]) * scale;
-#pragma unroll
-                for (int d = 0; d < ADH; ++d) if (d < dh) { dk[d] = __builtin_fmaf(dS, Qs[tq * dh + d], dk[d]); dv[d] = __builtin_fmaf(pd, Gs[tq * dh + d], dv[d]); }
+                pj[ps] = __expf(a * scale - lt);
+                if (thresh != 0) c = keep_elem(seed, (hb + t) * T + j, thresh) ? c * inv_keep : 0.f;
+                dp[ps] = c;
+                D = __builtin_fmaf(pj[ps], c, D);
             }
         }
-        float* drow = dqkv + ((size_t)j * B + b) * 3 * Z + h * dh;
+        D = wave_sum(D);
 #pragma unroll
-        for (int d = 0; d < ADH; ++d) if (d < dh) { drow[Z + d] = dk[d]; drow[2 * Z + d] = dv[d]; }
+        for (int ps = 0; ps < 2; ++ps) {
+            const int j = ps * 64 + lane;
+            if (j < T) S1[j] = pj[ps] * (dp[ps] - D) * scale;
+        }
+        if (lane == 0) Ds[t] = D;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < dh) {
+            float dq = 0.f;
+            for (int j = 0; j < jmax; ++j) dq = __builtin_fmaf(S1[j], Ks[j * rs + lane], dq);
+            dqkv[((size_t)t * B + b) * 3 * Z + h * dh + lane] = dq;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- phase 2: a wave per key j; lanes are the queries t >= j that see it ----
+    for (int j = wave; j < T; j += AW) {
+        const bool live = j < len;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int t = j + ps * 64 + lane;
+            if (t < T) {
+                float dS = 0.f, pd = 0.f;
+                if (live) {
+                    float a = 0.f, c = 0.f;
+                    for (int d = 0; d < dh; ++d) {
+                        a = __builtin_fmaf(Qs[t * rs + d], Ks[j * rs + d], a);
+                        c = __builtin_fmaf(Gs[t * rs + d], Vs[j * rs + d], c);
+                    }
+                    const float p = __expf(a * scale - Ls[t]);
+                    pd = p;
+                    if (thresh != 0) {
+                        const bool kp = keep_elem(seed, (hb + t) * T + j, thresh);
+                        c = kp ? c * inv_keep : 0.f;
+                        pd = kp ? p * inv_keep : 0.f;
+                    }
+                    dS = p * (c - Ds[t]) * scale;
+                }
+                S1[t] = dS;
+                S2[t] = pd;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < dh) {
+            float dk = 0.f, dv = 0.f;
+            for (int t = j; t < T; ++t) {
+                dk = __builtin_fmaf(S1[t], Qs[t * rs + lane], dk);
+                dv = __builtin_fmaf(S2[t], Gs[t * rs + lane], dv);
+            }
+            float* drow = dqkv + ((size_t)j * B + b) * 3 * Z + h * dh + lane;
+            drow[Z] = dk;
+            drow[2 * Z] = dv;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -336,7 +396,7 @@ int umlh_enc_launch_add_inplace(float* y, const float* x, long long n, hipStream
 
 int umlh_enc_launch_colsum(const float* x, int M, int N, float* out, hipStream_t st) {
     if (N <= 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, x, M, N, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(64 * CG), 0, st, x, M, N, out);
     return (int)hipGetLastError();
 }
 
@@ -351,7 +411,7 @@ int umlh_enc_launch_layernorm_bwd(const float* dy, const float* s, const float* 
                                   int M, int N, float* ds, float* dgamma, float* dbeta, hipStream_t st) {
     if (M <= 0) return 0;
     hipLaunchKernelGGL(layernorm_bwd_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, dy, s, gamma, mean, rstd, M, N, ds);
-    hipLaunchKernelGGL(layernorm_bwd_cols_kernel, dim3((N + 63) / 64), dim3(256), 0, st, dy, s, mean, rstd, M, N, dgamma, dbeta);
+    hipLaunchKernelGGL(layernorm_bwd_cols_kernel, dim3((N + 63) / 64), dim3(64 * CG), 0, st, dy, s, mean, rstd, M, N, dgamma, dbeta);
     return (int)hipGetLastError();
 }
 
@@ -374,25 +434,34 @@ int umlh_enc_launch_gather_rows(const float* x, const int64_t* idx, int n, int Z
 // returns hipErrorInvalidValue for shapes outside the kernel's envelope (T <= 128, head dim <= 64)
 int umlh_enc_launch_attention_fwd(const float* qkv, const int64_t* lengths, int T, int B, int Z, int H, float p,
                                   unsigned long long seed, float* ctx, float* lse, hipStream_t st) {
-    if (T < 1 || T > 128 || H < 1 || Z % H != 0 || Z / H > ADH) return (int)hipErrorInvalidValue;
-    const size_t smem = sizeof(float) * 2 * (size_t)T * (Z / H);
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(128), smem, st, qkv, lengths, T, B, Z, H, drop_thresh(p),
+    if (T < 1 || T > ATM || H < 1 || Z % H != 0 || Z / H > ADH) return (int)hipErrorInvalidValue;
+    const int rs = (Z / H) | 1;
+    const size_t smem = sizeof(float) * (3 * (size_t)T * rs + AW * T);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), smem, st, qkv, lengths, T, B, Z, H, drop_thresh(p),
                        p > 0.f ? 1.f / (1.f - p) : 1.f, seed, ctx, lse);
     return (int)hipGetLastError();
 }
 
 int umlh_enc_launch_attention_bwd(const float* qkv, const int64_t* lengths, const float* lse, const float* dctx, int T, int B,
                                   int Z, int H, float p, unsigned long long seed, float* dqkv, hipStream_t st) {
-    if (T < 1 || T > 128 || H < 1 || Z % H != 0 || Z / H > ADH) return (int)hipErrorInvalidValue;
-    const size_t smem = sizeof(float) * (4 * (size_t)T * (Z / H) + 2 * T);
+    if (T < 1 || T > ATM || H < 1 || Z % H != 0 || Z / H > ADH) return (int)hipErrorInvalidValue;
+    const int rs = (Z / H) | 1;
+    const size_t smem = sizeof(float) * (4 * (size_t)T * rs + 2 * T + AW * 2 * T);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(128), smem, st, qkv, lengths, lse, dctx, T, B, Z, H, drop_thresh(p),
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), smem, st, qkv, lengths, lse, dctx, T, B, Z, H, drop_thresh(p),
                        p > 0.f ? 1.f / (1.f - p) : 1.f, seed, dqkv);
     return (int)hipGetLastError();
 }

@@ -1,9 +1,12 @@
 // MultiBench alternation step: fused per-modality decoder Linear(z -> D) + masked next-step
 // MSE (MultiBench/models.py:202,213,234,243 + MSE :129-143) and its backward.
 // Shapes are tiny (B*T <= ~1600 rows, z <= 300, D <= 300): plain fp32, latency-bound, one
-// workgroup per sequence position; no MFMA reshaping.
+// workgroup per sequence position; only the decoder's dW (a [D x rows] x [rows x z] contraction) goes
+// through the fp32 MFMA GEMM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+#include "umlh_common.h"
 
 // row r = (b, t): recon[r][d] = bias[d] + sum_k z[r][k] W[d][k];  masked residual vs x[b][t+1].
 __global__ __launch_bounds__(128) void seq_mse_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w,
@@ -87,28 +90,33 @@ __global__ __launch_bounds__(128) void seq_mse_bwd_dz_kernel(const float* __rest
     }
 }
 
-// dW[d][k] = s * sum_r dres[r][d] z[r][k];  db[d] = s * sum_r dres[r][d]     (one block per d)
-__global__ __launch_bounds__(128) void seq_mse_bwd_dw_kernel(const float* __restrict__ dres, const float* __restrict__ z,
-                                                             const float* __restrict__ loss_cnt, const float* __restrict__ grad_out,
-                                                             int R, int Z, int D, float* __restrict__ dw, float* __restrict__ db) {
-    __shared__ float red[128];
-    const int d = blockIdx.x, tid = threadIdx.x;
-    const float s = 2.f * grad_out[0] / loss_cnt[1];
-    float bsum = 0.f;
-    for (int r = tid; r < R; r += 128) bsum += dres[(size_t)r * D + d];
-    for (int k = tid; k < Z; k += 128) {
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc = fmaf(dres[(size_t)r * D + d], z[(size_t)r * Z + k], acc);
-        dw[(size_t)d * Z + k] = acc * s;
-    }
-    red[tid] = bsum;
+// db[d] = s * sum_r dres[r][d]   (one block per 64 columns, 16 row groups, fixed order);  s = 2 * grad_out / count
+__global__ __launch_bounds__(1024) void seq_mse_bwd_db_kernel(const float* __restrict__ dres, const float* __restrict__ loss_cnt,
+                                                              const float* __restrict__ grad_out, int R, int D,
+                                                              float* __restrict__ db) {
+    __shared__ float sh[16][64];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6, d = blockIdx.x * 64 + l;
+    float a = 0.f;
+    if (d < D)
+        for (int r = g; r < R; r += 16) a += dres[(size_t)r * D + d];
+    sh[g][l] = a;
     __syncthreads();
-    for (int off = 64; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
+    if (g == 0 && d < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][l];
+        db[d] = t * (2.f * grad_out[0] / loss_cnt[1]);
     }
-    if (tid == 0) db[d] = red[0] * s;
 }
+
+// dw[i] *= s   (the dW GEMM runs with alpha = 1: s is a device-side scalar)
+__global__ __launch_bounds__(256) void seq_mse_scale_kernel(float* __restrict__ dw, long long n, const float* __restrict__ loss_cnt,
+                                                            const float* __restrict__ grad_out) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dw[i] *= 2.f * grad_out[0] / loss_cnt[1];
+}
+
+extern "C" int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream);
 
 extern "C" {
 int umlh_seq_launch_fwd(const float* z, const float* w, const float* b, const float* x, const int64_t* lengths, int B, int T,
@@ -121,7 +129,16 @@ int umlh_seq_launch_fwd(const float* z, const float* w, const float* b, const fl
 int umlh_seq_launch_bwd(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out, int B,
                         int T, int Z, int D, float* dz, float* dw, float* db, hipStream_t st) {
     hipLaunchKernelGGL(seq_mse_bwd_dz_kernel, dim3(B * T), dim3(128), sizeof(float) * D, st, dres, w, loss_cnt, grad_out, Z, D, dz);
-    hipLaunchKernelGGL(seq_mse_bwd_dw_kernel, dim3(D), dim3(128), 0, st, dres, z, loss_cnt, grad_out, B * T, Z, D, dw, db);
+    hipLaunchKernelGGL(seq_mse_bwd_db_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, dres, loss_cnt, grad_out, B * T, D, db);
+    // dW[d][k] = s * sum_r dres[r][d] z[r][k]: the transposed-A GEMM of the fp32 MFMA kernel, then the device-side scale
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dres; g.lda = D; g.B = z; g.ldb = Z; g.out = dw; g.ldo = Z;
+    g.M = D; g.N = Z; g.K = B * T; g.k_chunk = g.K; g.k_switch = g.K; g.k_valid1 = g.K; g.alpha = 1.f;
+    int rc = umlh_f32_launch_gemm(&g, 1, 1, 1, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(seq_mse_scale_kernel, dim3((unsigned)(((long long)D * Z + 255) / 256)), dim3(256), 0, st, dw, (long long)D * Z,
+                       loss_cnt, grad_out);
     return (int)hipGetLastError();
 }
 }
