@@ -234,9 +234,12 @@ int  umlh_seq_mse_backward(const float* z, const float* w, const float* dres, co
 
 /* out[m][n] = alpha * sum_k A(m,k) B(n,k).  ta = 0: A[m*lda + k], rows optionally gathered by a_rows[m];
  * ta = 1: A[k*lda + m].  tb = 0: B[n*ldb + k];  tb = 1: B[k*ldb + n], rows optionally gathered by k_rows[k].
- * (ta,tb) in {(0,0),(0,1),(1,1)}: y = x W^T, dx = dy W, dW = dy^T x.  fp32 MFMA (exact fp32 products). */
+ * (ta,tb) in {(0,0),(0,1),(1,1)}: y = x W^T, dx = dy W, dW = dy^T x.  fp32 MFMA (exact fp32 products).
+ * splits > 1: split-K over `splits` slabs of M*ldo floats in `slabs` (caller scratch), summed into out in slab
+ * order -- the encoder's GEMMs have few output tiles and a long K, so one tile per CU is latency-bound. */
 int  umlh_gemm_f32(const float* A, const float* B, float* out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
-                   int32_t ldo, int32_t ta, int32_t tb, const int64_t* a_rows, const int64_t* k_rows, float alpha, void* stream);
+                   int32_t ldo, int32_t ta, int32_t tb, const int64_t* a_rows, const int64_t* k_rows, float alpha,
+                   int32_t splits, float* slabs, void* stream);
 /* y[m][n] = act(y[m][n] + bias[n]) in place (bias may be NULL; relu != 0: max(.,0)) */
 int  umlh_bias_act(float* y, const float* bias, int64_t M, int32_t N, int32_t relu, void* stream);
 /* dy[i] = y[i] > 0 ? dy[i] : 0 in place */

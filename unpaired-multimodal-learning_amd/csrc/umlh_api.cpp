@@ -436,15 +436,27 @@ int umlh_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
 
 // ---- MultiBench shared encoder ops (kernels: umlh_kernels_enc.hip, GEMMs: gemm_f32) ----
 int umlh_gemm_f32(const float* A, const float* B, float* out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
-                  int32_t ldo, int32_t ta, int32_t tb, const int64_t* a_rows, const int64_t* k_rows, float alpha, void* stream) {
-    if (!A || !B || !out || M < 0 || N < 0 || K < 1 || (ta && a_rows) || (!tb && k_rows))
+                  int32_t ldo, int32_t ta, int32_t tb, const int64_t* a_rows, const int64_t* k_rows, float alpha,
+                  int32_t splits, float* slabs, void* stream) {
+    if (!A || !B || !out || M < 0 || N < 0 || K < 1 || (ta && a_rows) || (!tb && k_rows) || splits < 1 || (splits > 1 && !slabs))
         return fail(UMLH_E_INVALID, "umlh_gemm_f32: bad arguments");
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A = A; g.B = B; g.out = out; g.a_rows = a_rows; g.k_rows = k_rows;
+    g.A = A; g.B = B; g.a_rows = a_rows; g.k_rows = k_rows;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = ldo;
-    g.k_chunk = K; g.slab_stride = 0; g.alpha = alpha; g.k_switch = K; g.k_valid1 = K;
-    HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, 1, (hipStream_t)stream), "gemm_f32");
+    g.alpha = alpha; g.k_switch = K; g.k_valid1 = K;
+    if (splits == 1) {
+        g.out = out; g.k_chunk = K; g.slab_stride = 0;
+        HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, 1, (hipStream_t)stream), "gemm_f32");
+        return UMLH_OK;
+    }
+    const int chunk = (int)round_up((K + splits - 1) / splits, KT);
+    const int ns = (K + chunk - 1) / chunk;
+    g.out = slabs; g.k_chunk = chunk; g.slab_stride = (long long)M * ldo;
+    HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, ns, (hipStream_t)stream), "gemm_f32 (split-K)");
+    const long long n = (long long)M * ldo;
+    if (n > 0x7fffffffLL) return fail(UMLH_E_INVALID, "umlh_gemm_f32: output too large for the split-K reduce");
+    HIPCHK(umlh_enc_launch_colsum(slabs, ns, (int)n, out, (hipStream_t)stream), "split-K reduce");
     return UMLH_OK;
 }
 

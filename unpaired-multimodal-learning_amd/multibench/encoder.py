@@ -36,10 +36,21 @@ def _f32(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+def _splits(m, n, k):
+    """Split-K factor: these GEMMs have few 64x64 output tiles (z <= 300) and a long reduction (1600 token rows or
+    the 2048-wide FFN); one tile per CU walking K alone is latency-bound, so K is cut until ~2 tiles per CU."""
+    tiles = ((m + 63) // 64) * ((n + 63) // 64)
+    if k < 512 or tiles >= 512:
+        return 1
+    return max(1, min(8, k // 256, -(-512 // tiles)))
+
+
 def gemm(a, b, m, n, k, lda, ldb, ta, tb, a_rows=None, k_rows=None, alpha=1.0):
     out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    sp = _splits(m, n, k)
+    slabs = torch.empty(sp, m, n, dtype=torch.float32, device=a.device) if sp > 1 else None
     check(umlh.load_library().umlh_gemm_f32(_p(a), _p(b), _p(out), m, n, k, lda, ldb, n, ta, tb, _p(a_rows), _p(k_rows),
-                                            float(alpha), _st(a.device)), "umlh_gemm_f32")
+                                            float(alpha), sp, _p(slabs), _st(a.device)), "umlh_gemm_f32")
     return out
 
 

@@ -112,7 +112,7 @@ def load_library():
     lib.umlh_bind.argtypes = [vp, C.POINTER(Buffers)]
     lib.umlh_enable_diagnostics.argtypes = [vp, C.c_int32]
     i32, f32 = C.c_int32, C.c_float
-    lib.umlh_gemm_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp]
+    lib.umlh_gemm_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]
     lib.umlh_bias_act.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.umlh_add_inplace.argtypes = [vp, vp, i64, vp]
     lib.umlh_relu_backward.argtypes = [vp, vp, i64, vp]
