@@ -224,23 +224,27 @@ class EncoderFn(torch.autograd.Function):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x w^T + b over the trailing dimension (the per-modality in/out projections, models.py:7-35)."""
+    """y = act(x w^T + b) over the trailing dimension (the per-modality in/out projections, models.py:7-35; with
+    ``relu`` the Linear+ReLU pairs of the Gaussian toy's shared encoder/decoder)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, relu=False):
         x2 = _f32(x).reshape(-1, x.shape[-1])
         w2, b2 = _f32(w), (None if b is None else _f32(b))
-        y = linear_forward(x2, w2, b2)
-        ctx.save_for_backward(x2, w2)
-        ctx.has_bias, ctx.shape, ctx.need_dx = b is not None, x.shape, x.requires_grad
+        y = linear_forward(x2, w2, b2, relu=relu)
+        ctx.save_for_backward(x2, w2, y if relu else None)
+        ctx.has_bias, ctx.shape, ctx.need_dx, ctx.relu = b is not None, x.shape, x.requires_grad, relu
         return y.reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
-        x2, w2 = ctx.saved_tensors
+        x2, w2, y = ctx.saved_tensors
         dy = _f32(gy).reshape(-1, w2.shape[0])
+        if ctx.relu:
+            dy = dy.clone()
+            check(umlh.load_library().umlh_relu_backward(_p(y), _p(dy), dy.numel(), _st(dy.device)), "umlh_relu_backward")
         dx, dw, db = linear_backward(x2, w2, dy, need_dx=ctx.need_dx, has_bias=ctx.has_bias)
-        return (None if dx is None else dx.reshape(ctx.shape)), dw, db
+        return (None if dx is None else dx.reshape(ctx.shape)), dw, db, None
 
 
 def layer_params(layer):
