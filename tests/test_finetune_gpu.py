@@ -167,3 +167,67 @@ def test_sweep_farm_equals_isolated_runs(tmp_path):
     # a second sweep finds every result file and skips the work (reference finetune.py:330-333)
     res2, _, _ = ft.sweep(datasets, grid, args_for(tmp_path / "farm", 4))
     assert res2["val_acc"] == res["val_acc"]
+
+
+@pytest.mark.parametrize("tag", ["lin_zs", "mlp_lt"])
+def test_logger_receives_reference_diagnostics(tag):
+    """With a logger, train() logs per step what the reference logs (finetune.py:236-240): losses, accuracies, lr, the
+    gradient diagnostics and feature_direction_sim (checked against numpy on the reference's recorded batches)."""
+    import finetune as ft
+    from engine.datasets.utils import FeatureLoader, FeatureTable, TextTensorDataset
+    from engine.models.head import UML
+    from engine.optimizer.optim import build_optimizer
+    from engine.optimizer.scheduler import build_lr_scheduler
+    from engine.tools.utils import set_random_seed
+    g = load_golden("train_" + tag)
+    (d_img, text_indim, C, B, max_iters, eval_freq, patience, lr, wd, alpha, learnable, zeroshot, seed) = g["cfg"]
+    d_img, text_indim, C, B, seed = map(int, (d_img, text_indim, C, B, seed))
+    T = torch.as_tensor
+    set_random_seed(seed)
+    text_ds = TextTensorDataset(T(g["x_txt"]), T(g["y_txt"]), torch.zeros(len(g["y_txt"]), dtype=torch.long))
+    model = UML(d_img, text_indim, C, bias=False, learnable_temp=bool(learnable)).to(DEV)
+    if zeroshot:
+        model.zero_shot_init(text_ds)
+    optimizer = build_optimizer(model.parameters(), str(g["optim"]), float(lr), float(wd))
+    scheduler = build_lr_scheduler(optimizer, "cosine", 50, int(max_iters), warmup_type="linear", warmup_lr=1e-5)
+    il = FeatureLoader(FeatureTable(T(g["x_img"]), T(g["y_img"]), DEV), B, shuffle=True, kind="image")
+    tl = FeatureLoader(FeatureTable(text_ds.input_tensor, text_ds.label_tensor, DEV), B, shuffle=True, kind="text")
+    vl = FeatureLoader(FeatureTable(T(g["x_val"]), T(g["y_val"]), DEV), B, shuffle=False)
+    tel = FeatureLoader(FeatureTable(T(g["x_test"]), T(g["y_test"]), DEV), B, shuffle=False)   # its iter() draws RNG too
+
+    class Log:
+        def __init__(self):
+            self.rows = []
+
+        def log(self, d):
+            self.rows.append(d)
+    lg = Log()
+    n = 12
+    ft.train(model, il, tl, vl, tel, optimizer, scheduler, device=DEV, max_iters=n, alpha=float(alpha), eval_freq=int(eval_freq),
+             patience=100, logger=lg)
+    steps = [r for r in lg.rows if "train/image_loss" in r]
+    assert len(steps) == n
+    gd, ce = g["grad_diag"], g["train_ce"]
+    n_img = len(g["y_img"])
+    for k, r in enumerate(steps):
+        assert abs(r["train/image_loss"] - ce[2 * k]) < 1e-4 and abs(r["train/text_loss"] - ce[2 * k + 1]) < 1e-4
+        assert abs(r["train/grad_direction_sim"] - gd[k, 0]) < 5e-4 and abs(r["train/grad_agreement_rate"] - gd[k, 1]) < 5e-3
+        assert abs(r["train/img_grad_norm"] - gd[k, 2]) < 2e-3 * gd[k, 2] + 1e-7
+    # feature_direction_sim: batches in the reference's order (the recorded sampler indices); with img_proj only step 0
+    # uses known (initial) projection weights
+    def batches(idx, n_rows):                     # DataLoader(drop_last=False): every epoch ends with the short batch
+        out, pos = [], 0
+        while len(out) < n:
+            for s in range(0, n_rows, B):
+                m = min(B, n_rows - s)
+                out.append(idx[pos:pos + m])
+                pos += m
+        return out
+    bi_all, bt_all = batches(g["idx_img"], n_img), batches(g["idx_txt"], len(g["y_txt"]))
+    for k in range(n if text_indim == 0 else 1):
+        fi = g["x_img"][bi_all[k]]
+        if text_indim > 0:
+            fi = fi @ g["w_proj_init"].T
+        fim, ftm = fi.mean(0), g["x_txt"][bt_all[k]].mean(0)
+        ref = float(fim @ ftm / (np.linalg.norm(fim) * np.linalg.norm(ftm)))
+        assert abs(steps[k]["train/feature_direction_sim"] - ref) < 1e-4, k

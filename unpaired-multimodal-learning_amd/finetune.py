@@ -85,6 +85,24 @@ class _Reiter:
         return self.make()
 
 
+def _rows(rb):
+    return rb.feats if rb.index is None else umlh.gather_rows(rb.feats, rb.index)
+
+
+def feature_direction_sim(model, img_rows, txt_rows):
+    """cos(mean image feature after extract_features, mean text feature) of one step's batches
+    (finetune.py:182-183,239); 0 without text.  Row gather, projection and the column sums run on the HIP ops;
+    the final ratio is formed on the host from the two d-vectors."""
+    if img_rows is None or txt_rows is None:
+        return 0.0
+    n_of = lambda rb: rb.feats.shape[0] if rb.index is None else rb.index.numel()
+    with torch.no_grad():
+        fi = umlh.column_sums(model.extract_features(_rows(img_rows)).contiguous()).double().cpu() / n_of(img_rows)
+        ft = umlh.column_sums(_rows(txt_rows)).double().cpu() / n_of(txt_rows)
+    den = float(fi.norm() * ft.norm())
+    return float(fi @ ft) / den if den > 0 else float("nan")
+
+
 def _state_dict_cpu(model):
     return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
@@ -136,6 +154,8 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
         else:
             img_rows = img_src.next() if img_src is not None else None
             txt_rows = txt_src.next() if txt_src is not None else None
+            if logger is not None:                   # with the pre-update projection, as the reference (:182-183)
+                feat_sim = feature_direction_sim(model, img_rows, txt_rows)
             engine.train_step(img_rows, txt_rows, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1,
                               alpha=alpha, img_alpha=img_alpha, scalars_out=scalars[i])
             optimizer.step_count += 1
@@ -150,7 +170,8 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
                         "train/image_acc": float(s[umlh.S_ACC_IMG]), "train/text_acc": float(s[umlh.S_ACC_TXT]),
                         "train/lr": scheduler.get_last_lr()[0],
                         "train/grad_direction_sim": gd["grad_direction_sim"], "train/img_grad_norm": gd["img_grad_norm"],
-                        "train/txt_grad_norm": gd["txt_grad_norm"], "train/grad_agreement_rate": gd["grad_agreement_rate"]})
+                        "train/txt_grad_norm": gd["txt_grad_norm"], "train/grad_agreement_rate": gd["grad_agreement_rate"],
+                        "train/feature_direction_sim": feat_sim})
         if i % eval_freq == 0:
             state_dict_cpu = _state_dict_cpu(model)
             val_loss, val_acc = validate(model, val_loader, device=device)

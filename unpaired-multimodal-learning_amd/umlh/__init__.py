@@ -8,5 +8,6 @@ creating a handle fails loudly without a GPU.
 from ._lib import (UmlhError, build_library, lib_path, load_library, OPT_IDS, PREC_IDS,  # noqa: F401
                    N_SCALARS, S_LOSS_IMG, S_LOSS_TXT, S_ACC_IMG, S_ACC_TXT, S_GSCALE_IMG, S_GSCALE_TXT,
                    S_CORRECT, S_LOSS_SUM, S_GRAD_DOT, S_GRAD_N2_IMG, S_GRAD_N2_TXT, S_GRAD_AGREE, N_CORE_SCALARS)
-from .head_engine import HeadEngine, RowBatch, grad_diagnostics, optimizer_step, random_permutation, to_bf16  # noqa: F401
+from .head_engine import (HeadEngine, RowBatch, column_sums, gather_rows, grad_diagnostics, optimizer_step,  # noqa: F401
+                          random_permutation, to_bf16)
 from .dp import DataParallelStepper  # noqa: F401,E402

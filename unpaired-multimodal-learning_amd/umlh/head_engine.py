@@ -307,6 +307,24 @@ def grad_diagnostics(scalars, n_elements: int, rows_img: int = 1, rows_txt: int 
     }
 
 
+def gather_rows(x: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """out[j] = x[index[j]] for a contiguous fp32 [N, d] device table (``umlh_gather_rows``)."""
+    lib = _lib.load_library()
+    out = torch.empty(index.numel(), x.shape[1], dtype=torch.float32, device=x.device)
+    st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    check(lib.umlh_gather_rows(_ptr(x), _ptr(index), index.numel(), x.shape[1], _ptr(out), 0, st), "umlh_gather_rows")
+    return out
+
+
+def column_sums(x: torch.Tensor) -> torch.Tensor:
+    """sum over the rows of a contiguous fp32 [M, N] device matrix (``umlh_colsum``)."""
+    lib = _lib.load_library()
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    check(lib.umlh_colsum(_ptr(x), x.shape[0], x.shape[1], _ptr(out), st), "umlh_colsum")
+    return out
+
+
 def optimizer_step(name: str, param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: Optional[torch.Tensor], *,
                    lr: float, step: int, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
                    momentum: float = 0.9) -> None:
