@@ -57,11 +57,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    n_dev = torch.cuda.device_count()
+    # one rank per GPU (RCCL over xGMI).  Rehearsal on a box with fewer GPUs than ranks: ranks share GPUs and the
+    # gradient all-reduce goes through gloo (RCCL refuses two ranks on one device) -- functional check only.
+    rehearsal = world > n_dev
+    dev = torch.device("cuda", local % max(1, n_dev))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import umlh
     from engine.datasets.utils import FeatureLoader, FeatureTable
@@ -218,8 +225,8 @@ def main():
                                       "C=1000, 4096 img + 4096 txt rows/step/GPU, scale 100, zero-shot init, AdamW "
                                       "lr 1e-3 wd 0.01, warm-up 50 + cosine 12800",
                           "n_img_rows": N_IMG, "n_txt_rows": N_TXT, "global_batch": 2 * BATCH * world,
-                          "parallelism": f"dp{world}", "precision_mode": args.precision, "order_rng": args.order_rng,
-                          "steps_per_call": args.block},
+                          "parallelism": f"dp{world}" + (" (REHEARSAL: ranks share GPUs, gloo all-reduce -- not a measurement)" if rehearsal else ""),
+                          "precision_mode": args.precision, "order_rng": args.order_rng, "steps_per_call": args.block},
                "final_loss": {"img": round(final[0], 4), "txt": round(final[1], 4)},
                "host_enqueue_ms_per_step": round(head["host_enqueue_ms_per_step"], 4),
                "roofline": roofline, "cpu_baseline": cpu}
