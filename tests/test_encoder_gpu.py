@@ -46,11 +46,13 @@ def _torch_reference(m, x, lengths):
     (3, 9, 20, 20, 5, 1, False, False, False, False, True),
     (8, 16, 12, 150, 5, 2, True, False, False, True, False),
     (5, 33, 7, 300, 5, 1, True, True, True, False, True),
+    (2, 128, 16, 320, 5, 1, True, True, False, True, True),     # the attention kernel's envelope: T = 128, head dim 64
+    (3, 1, 8, 20, 5, 1, True, True, True, True, False),         # single-token sequences
 ])
 def test_encoder_forward_backward_vs_torch(B, T, F, Z, H, L, conv, pos, learn, out_last, use_len):
     from multibench.models import Transformer
     torch.manual_seed(B * 1000 + T)
-    m = Transformer(F, Z, nhead=H, num_layers=L, conv1d=conv, out_last=out_last, pos_embd=pos, pos_learnable=learn, max_len=64).to(DEV)
+    m = Transformer(F, Z, nhead=H, num_layers=L, conv1d=conv, out_last=out_last, pos_embd=pos, pos_learnable=learn, max_len=128).to(DEV)
     m.eval()                                                  # dropout off: torch's Philox masks cannot be reproduced
     with torch.no_grad():                                     # make every parameter matter (norm scales != 1, biases != 0)
         for p in m.parameters():
