@@ -44,6 +44,9 @@ def run(tag, d_img, d_sh, C, B, proj, precision, n_img=65536, n_txt=8192, steps=
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "half-classes":   # what-if probe for a class-split forward
+        run("probe: C=500 linear head bf16, batch 4096+4096", 512, 512, 500, 4096, False, "bf16", steps=60)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cfg3-bf16":      # single config, e.g. under rocprofv3
         run("cfg3 DINOv2-L + OpenLLaMA two-layer head, batch 4096+4096", 1024, 3200, 1000, 4096, True, "bf16", steps=40)
         sys.exit(0)
