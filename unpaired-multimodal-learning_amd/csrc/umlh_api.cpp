@@ -161,6 +161,7 @@ struct umlh_handle_s {
     float* diag_dst;            // this step's 4 gradient-diagnostic accumulators (zeroed by the forward kernel)
     int n_slabs_img;            // dW_head slabs that hold image rows (the rest hold text rows)
     bool diagnostics;           // umlh_enable_diagnostics
+    int dbg_fwd, dbg_dw;        // timing-only ablation / cycle-stamp switches (UMLH_DBG_FWD / UMLH_DBG_DW), read once at create
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
     bool profiling;
 };
@@ -205,6 +206,8 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     if (cfg->precision == UMLH_PREC_BF16) {
         // two 32-sample tiles per wave would halve the L2->CU stream of the head weight, but measured
         // slower on MI355X (51 vs 26 us at cfg2: half the CUs idle, VGPR-limited ring) -> opt-in only
+        { const char* d = getenv("UMLH_DBG_FWD"); h->dbg_fwd = d ? atoi(d) : 0; }
+        { const char* d = getenv("UMLH_DBG_DW"); h->dbg_dw = d ? atoi(d) : 0; }
         const char* e = getenv("UMLH_BF16_STW");
         int want = e ? atoi(e) : 1;
         if (h->wc == 8 && h->ctw >= 2 && want == 2) h->stw = 2;
@@ -579,7 +582,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             DwArgsB g;
             memset(&g, 0, sizeof(g));
             g.zeros = zeros16; g.bcs = 64; g.a_rows = iota; g.nsplit = g.nsplit1 = 1;
-            { const char* e = getenv("UMLH_DBG_DW"); g.dbg = e ? atoi(e) : 0; }
+            g.dbg = h->dbg_dw;
             if (g.dbg >= 16) { g.dbg -= 16; g.stamps = reinterpret_cast<unsigned long long*>(ws(h, L.dbg)); }   // +16: cycle stamps
             return g;
         };
@@ -627,7 +630,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         fb.W = w16; fb.C = c.num_classes; fb.K = c.d_shared;
         fb.dzt = want_grad ? dz16 : nullptr; fb.crows = crows;
         fb.partials = ws(h, L.partials);
-        { const char* e = getenv("UMLH_DBG_FWD"); fb.dbg = e ? atoi(e) : 0; }
+        fb.dbg = h->dbg_fwd;
         fb.learn = c.learnable_temp;
         fb.diag_zero = h->diag_dst;
         fb.stamps = fb.dbg == 9 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
