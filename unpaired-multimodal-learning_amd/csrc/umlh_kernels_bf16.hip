@@ -689,21 +689,29 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
             const u16* f_frag = Ft[buf] + f_off;
             const int rids[2] = {ids[cnext * DKT + f_row[0]], ids[cnext * DKT + f_row[1]]};
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // row ids of the chunk to fetch
+            // fragments are read one k-step ahead of their MFMAs (two register sets): only the first k-step of
+            // a chunk -- right after the barrier that publishes its buffer -- waits on LDS latency
+            bf16x8 av[2][2], bvv[2];
+            auto load_frag = [&](int ks, int slot) {
 #pragma unroll
-            for (int ks = 0; ks < DKT / 16; ++ks) {
-                bf16x8 av[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(a_frag + i * 32 * RSA + ks * 16);
+                for (int i = 0; i < 2; ++i) av[slot][i] = *reinterpret_cast<const bf16x8*>(a_frag + i * 32 * RSA + ks * 16);
                 const u16* base = f_frag + ks * 16 * RSF;
                 s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
                 s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * RSF));
                 s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const bf16x8 bv = __builtin_bit_cast(bf16x8, v);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv, acc[0], 0, 0, 0);
+                bvv[slot] = __builtin_bit_cast(bf16x8, v);
+            };
+            load_frag(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int ks = 0; ks < DKT / 16; ++ks) {
+                const int cur = ks & 1;
+                if (ks + 1 < DKT / 16) load_frag(ks + 1, cur ^ 1);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][0], bvv[cur], acc[0], 0, 0, 0);
                 store_piece(st[nd], nbuf, ks);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][1], bvv[cur], acc[1], 0, 0, 0);
                 load_piece(st[nd], cnext, ks, rids);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // fragment reads
+                if (ks + 1 < DKT / 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next k-step's fragment reads
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // ds_write of the staged piece
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
