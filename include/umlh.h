@@ -199,6 +199,12 @@ int  umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hyper, float* scalar
  * per-batch means (finetune.py:311-312). */
 int  umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* batch, float* scalars_out, void* stream);
 
+/* Whole-table evaluation: the same forward as umlh_eval_batch over up to max_rows_img rows, but the per-row
+ * results are kept -- row_stats[2*r] = CE of row r, row_stats[2*r + 1] = 1 if its first arg-max is the label.
+ * validate() (finetune.py:291-315) forms its per-batch mean losses from these for ANY batch size, so a
+ * validation pass is one launch per 4096-row slab instead of one per batch. */
+int  umlh_eval_rows(umlh_handle_t h, const umlh_batch_t* rows, float* row_stats, void* stream);
+
 /* Per-phase device timing of umlh_train_step / umlh_grad_step with HIP events recorded
  * on the step's stream (bench.py's roofline leg; rocprofv3 --kernel-trace must agree).
  * Phases: 0 img_proj forward GEMM, 1 fused forward+CE, 2 dW_head GEMM, 3 img_proj

@@ -271,3 +271,35 @@ def test_device_permutation_is_a_bijection_and_seed_dependent():
                        order_rng="device")
     seen = torch.cat(list(ld.iter_index()))
     assert seen.numel() == 1000 and torch.equal(torch.sort(seen).values, torch.arange(1000, device=DEV))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_eval_rows_per_row_stats(precision):
+    """umlh_eval_rows: per-row CE and top-1 flag of a whole slab in one launch == the oracle's per-row values; the
+    per-batch means validate() forms from them == O.validate (finetune.py:291-315) for a batch size that divides
+    nothing (37)."""
+    import umlh
+    rng = np.random.default_rng(5)
+    d, C, n = 128, 100, 333
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = rng.integers(0, C, n)
+    w = rng.standard_normal((C, d)).astype(np.float32)
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    e = umlh.HeadEngine(d, d, C, max_rows_img=512, max_rows_txt=32, precision=precision, device=DEV)
+    e.w_head.copy_(torch.from_numpy(w))
+    e.scales.fill_(30.0)
+    T = lambda a, t: torch.as_tensor(np.ascontiguousarray(a)).to(DEV, t).contiguous()
+    st = e.eval_rows(umlh.RowBatch(T(x, torch.float32), T(y, torch.int64))).cpu().numpy()
+    rnd = (lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()) if precision == "bf16" else (lambda a: a)
+    z = (rnd(x) @ rnd(w).T) * 30.0
+    zmax = z.max(1, keepdims=True)
+    ce = (np.log(np.exp(z - zmax).sum(1)) + zmax[:, 0] - z[np.arange(n), y])
+    tol = 2e-3 if precision == "bf16" else 1e-4
+    np.testing.assert_allclose(st[:, 0], ce, atol=tol)
+    assert (st[:, 1] == (z.argmax(1) == y)).mean() > (0.99 if precision == "bf16" else 0.999999)
+    if precision == "fp32":
+        bs = 37
+        loss = np.mean([st[s:s + bs, 0].mean() for s in range(0, n, bs)])
+        ol, oa = O.validate(O.HeadState(w, None, 30.0, 30.0, False), x, y, bs, rng_draw=False)
+        assert abs(loss - ol) < 1e-4 and abs(st[:, 1].mean() - oa) < 1e-6

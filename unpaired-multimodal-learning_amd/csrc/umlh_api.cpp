@@ -161,6 +161,7 @@ struct umlh_handle_s {
     float* diag_dst;            // this step's 4 gradient-diagnostic accumulators (zeroed by the forward kernel)
     int n_slabs_img;            // dW_head slabs that hold image rows (the rest hold text rows)
     bool diagnostics;           // umlh_enable_diagnostics
+    float* row_stats;           // per-row {CE, correct} output of the next forward (umlh_eval_rows), else NULL
     int dbg_fwd, dbg_dw;        // timing-only ablation / cycle-stamp switches (UMLH_DBG_FWD / UMLH_DBG_DW), read once at create
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
     bool profiling;
@@ -633,6 +634,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         fb.dbg = h->dbg_fwd;
         fb.learn = c.learnable_temp;
         fb.diag_zero = h->diag_dst;
+        fb.row_stats = h->row_stats;
         fb.stamps = fb.dbg == 9 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
         mark(h, 2, st);
@@ -720,6 +722,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     fa.dzt = want_grad ? dzt : nullptr; fa.ldz = L.ldz;
     fa.partials = ws(h, L.partials);
     fa.diag_zero = h->diag_dst;
+    fa.row_stats = h->row_stats;
     HIPCHK(umlh_f32_launch_fwd(&fa, h->ctw, h->wc, nb0 + nb1, st), "fwd_ce");
     mark(h, 2, st);
     if (!want_grad) return UMLH_OK;
@@ -983,4 +986,22 @@ int umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* b, float* scalars_out, 
     FinalizeArgs f = make_finalize(h, b, nullptr, &hy, true, scalars_out, false);
     HIPCHK(umlh_launch_finalize(&f, st), "finalize");
     return UMLH_OK;
+}
+
+int umlh_eval_rows(umlh_handle_t h, const umlh_batch_t* b, float* row_stats, void* stream) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_eval_rows: handle not bound");
+    if (!b || !row_stats) return fail(UMLH_E_INVALID, "umlh_eval_rows: null argument");
+    int rc = check_batch(h, b, h->cfg.max_rows_img, "umlh_eval_rows");
+    if (rc) return rc;
+    if (b->rows == 0) return fail(UMLH_E_INVALID, "umlh_eval_rows: empty batch");
+    umlh_hyper_t hy;
+    memset(&hy, 0, sizeof(hy));
+    hy.lr = 0; hy.step = 1; hy.alpha = 1.f; hy.img_alpha = 1.f;
+    int sh = 0, sp = 0;
+    h->shadow_fresh = false;
+    h->diag_dst = nullptr;
+    h->row_stats = row_stats;
+    rc = forward_backward(h, b, nullptr, &hy, false, (hipStream_t)stream, &sh, &sp);
+    h->row_stats = nullptr;
+    return rc;
 }

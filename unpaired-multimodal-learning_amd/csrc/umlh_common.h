@@ -36,6 +36,7 @@ struct FwdArgs {
     int   ldz;
     float* partials;             // [grid][4] = {loss_sum, correct, gscale_sum, 0}
     float* diag_zero;            // 4 floats zeroed by block 0 (gradient-diagnostic accumulators of this step), or NULL
+    float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
 };
 
 // ---- generic fp32 GEMM: out[m][n] = alpha * sum_k A(m,k) * B(n,k) ----
@@ -84,6 +85,7 @@ struct FwdArgsB {
     int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
     unsigned long long* stamps;  // diagnostic build only (UMLH_DBG_FWD=9): [grid][8] s_memtime stamps of wave 0
     float* diag_zero;            // 4 floats zeroed by block 0 (gradient-diagnostic accumulators of this step), or NULL
+    float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
 };
 
 // bf16 GEMM out[m][n] = sum_k A[m][k] * B[k][n] (kernel dw_bf16<AM, OM>).  Written for dW = dZ^T F; the 2-layer

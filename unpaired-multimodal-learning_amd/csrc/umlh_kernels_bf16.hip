@@ -480,9 +480,15 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         }
         STAMP(4);
         if (wc == 0 && h == 0 && valid) {
-            bl += __logf(se) + mx - zy;
+            const float ce = __logf(se) + mx - zy;
+            bl += ce;
             bc += hit ? 1.f : 0.f;
             bg += sgn * (serw / se - rawy);
+            if (a.row_stats != nullptr) {
+                float* rs = a.row_stats + 2 * ((size_t)(sidx ? a.seg[0].rows : 0) + r);
+                rs[0] = ce;
+                rs[1] = hit ? 1.f : 0.f;
+            }
         }
     }
 #pragma unroll

@@ -271,6 +271,11 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
         vl = logf(se) + mx - zy;
         vc = (mi == lab) ? 1.f : 0.f;
         vg = serw / se - rawy;
+        if (a.row_stats != nullptr) {
+            float* rs = a.row_stats + 2 * ((size_t)(sidx ? a.seg[0].rows : 0) + r);
+            rs[0] = vl;
+            rs[1] = vc;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

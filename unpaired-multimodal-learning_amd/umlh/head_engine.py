@@ -281,6 +281,15 @@ class HeadEngine:
         check(self.lib.umlh_profile_read(self.handle, ms), "umlh_profile_read")
         return dict(zip(self.PHASES, [float(x) for x in ms]))
 
+    def eval_rows(self, batch: RowBatch, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Per-row {CE, top-1 correct} of up to ``max_rows_img`` rows in one forward launch (``umlh_eval_rows``)."""
+        b = self._batch(batch, self.d_img)
+        n = batch.n_rows()
+        if out is None:
+            out = torch.empty(n, 2, dtype=torch.float32, device=self.device)
+        check(self.lib.umlh_eval_rows(self.handle, self._ref(b), _ptr(out), self._stream()), "umlh_eval_rows")
+        return out
+
     def eval_batch(self, batch: RowBatch, scalars_out: Optional[torch.Tensor] = None):
         b = self._batch(batch, self.d_img)
         so = scalars_out if scalars_out is not None else self._scalars
