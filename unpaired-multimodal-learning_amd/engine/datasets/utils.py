@@ -171,3 +171,27 @@ class _IndexIter:
         idx = self.order[self.pos:self.pos + bs]
         self.pos += bs
         return idx
+
+    # -- bulk access for the blockwise training loop: many consecutive batches of the CURRENT epoch as one slice --
+    def remaining(self):
+        """Batches left in the current epoch that ``__next__`` would deliver without raising (0 before the first
+        batch of an epoch has been drawn: that call draws the sampler seed and must go through ``__next__``)."""
+        if self.order is None:
+            return 0
+        ld = self.loader
+        n, bs = len(ld.table), ld.batch_size
+        left = n - self.pos
+        return max(0, left // bs if ld.drop_last else (left + bs - 1) // bs)
+
+    def take_span(self, k):
+        """The next ``k <= remaining()`` batches as (one index slice, [batch sizes])."""
+        ld = self.loader
+        n, bs = len(ld.table), ld.batch_size
+        end = min(n, self.pos + k * bs)
+        idx = self.order[self.pos:end]
+        sizes = [bs] * ((end - self.pos) // bs)
+        if (end - self.pos) % bs:
+            sizes.append((end - self.pos) % bs)
+        assert len(sizes) == k
+        self.pos = end
+        return idx, sizes

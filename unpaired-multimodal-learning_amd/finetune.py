@@ -60,6 +60,12 @@ class _RowSource:
         idx, self.it = fetch_next(_Reiter(self._make_iter), self.it)
         return idx
 
+    def remaining(self):
+        return self.it.remaining() if self.indexed and hasattr(self.it, "remaining") else 0
+
+    def take_span(self, k):
+        return self.it.take_span(k)
+
     def table(self, precision):
         t = self.loader.table
         return (t.features, t.labels, t.features_bf16()) if precision == "bf16" else (t.features, t.labels)
@@ -138,11 +144,24 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
             n = i_end - i + 1
             bi = [] if img_src is not None else None
             bt = [] if txt_src is not None else None
-            for _ in range(n):                       # image then text per step: the reference's draw order
-                if img_src is not None:
-                    bi.append(img_src.next_index())
-                if txt_src is not None:
-                    bt.append(txt_src.next_index())
+            k = 0
+            while k < n:
+                # consecutive batches inside both loaders' current epochs are taken as ONE index slice each; a step
+                # at which a loader starts an epoch goes through next_index() -- image then text, the reference's
+                # draw order (finetune.py:164-174) -- so the RNG protocol is untouched
+                span = min([n - k] + [src.remaining() for src in (img_src, txt_src) if src is not None])
+                if span == 0:
+                    if img_src is not None:
+                        bi.append(img_src.next_index())
+                    if txt_src is not None:
+                        bt.append(txt_src.next_index())
+                    k += 1
+                else:
+                    if img_src is not None:
+                        bi.append(img_src.take_span(span))
+                    if txt_src is not None:
+                        bt.append(txt_src.take_span(span))
+                    k += span
             lrs = scheduler.lr_table(n)
             engine.train_steps(img_src.table(precision) if img_src else None, bi,
                                txt_src.table(precision) if txt_src else None, bt, lrs,
@@ -410,7 +429,10 @@ def sweep_farm(datasets, hyperparams, args, workers):
     (batch 32: a handful of workgroups per kernel).  The tables are uploaded once; every grid point
     gets its own engine, its own HIP stream and a host thread that enqueues whole evaluation
     intervals through ``umlh_train_steps`` (a C loop, no GIL), so the small kernels of different
-    points overlap on the chip.  No collective, no shared mutable state.
+    points can overlap on the chip.  No collective, no shared mutable state.  Measured on MI355X this
+    does not beat the sequential sweep for batch-32 steps -- the dispatch rate of dependent small kernels is the
+    limit -- so ``sweep_workers`` defaults to 1; the farm is for grids whose steps are large enough to be GPU-bound
+    individually yet too small to fill the chip.
 
     Unlike the sequential sweep -- where point k's shuffles depend on how much global RNG the
     points before it consumed -- every point draws from a private generator seeded by
@@ -465,8 +487,14 @@ def sweep_farm(datasets, hyperparams, args, workers):
         torch.save(test_dict, test_path)
         return test_dict
 
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        outs = list(pool.map(run, jobs))
+    import threading
+    import umlh.head_engine as _he
+    _he.ENQUEUE_LOCK = threading.Lock()
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            outs = list(pool.map(run, jobs))
+    finally:
+        _he.ENQUEUE_LOCK = None
     results = {"test_acc": [o["test_acc"] for o in outs], "val_acc": [o["val_acc"] for o in outs],
                "hparams": points, "model_records": []}
     return _report(results, args)

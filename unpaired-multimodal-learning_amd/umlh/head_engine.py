@@ -16,6 +16,12 @@ from . import _lib
 from ._lib import Batch, Buffers, Config, Hyper, OPT_IDS, PREC_IDS, N_SCALARS, Stream, UmlhError, check
 
 
+# Set by finetune.sweep_farm for its duration: worker threads take it around their multi-step enqueue calls.  Many
+# threads launching kernels at once contend inside the HIP runtime (measured: 12 free-running workers are 1.5x SLOWER
+# than one); serialised enqueues keep the single-thread launch rate while the streams still overlap on the GPU.
+ENQUEUE_LOCK = None
+
+
 @dataclass
 class RowBatch:
     """Rows of one modality for one step: a device-resident (feats, labels) table and
@@ -185,7 +191,8 @@ class HeadEngine:
                     alpha: float = 1.0, img_alpha: float = 1.0, scalars_out: Optional[torch.Tensor] = None) -> None:
         """``len(lrs)`` consecutive fused steps with no Python in between (umlh_train_steps).
         ``*_table`` = (feats, labels[, feats_bf16]) device tensors or None; ``*_index_batches``
-        = one int64 device index vector per step."""
+        = one int64 device index vector per step, or (index slice, [batch sizes]) entries that each cover
+        several consecutive steps."""
         n = len(lrs)
 
         def stream(table, batches, dim, cap):
@@ -197,12 +204,22 @@ class HeadEngine:
                 raise UmlhError("train_steps: table must be contiguous fp32 [N,dim] + int64 labels")
             if self.precision == "bf16" and (f16 is None or f16.dtype != torch.bfloat16 or f16.shape != f.shape):
                 raise UmlhError("train_steps: bf16 engine needs the table's bf16 shadow")
-            if len(batches) != n:
+            # an entry is one step's index vector, or (index slice, [sizes]) covering several consecutive steps
+            parts, sizes = [], []
+            for b in batches:
+                if isinstance(b, tuple):
+                    parts.append(b[0])
+                    sizes.extend(int(z) for z in b[1])
+                else:
+                    parts.append(b)
+                    sizes.append(int(b.numel()))
+            if len(sizes) != n:
                 raise UmlhError("train_steps: one index vector per step required")
-            sizes = [int(b.numel()) for b in batches]
             if max(sizes) > cap:
                 raise UmlhError(f"train_steps: batch of {max(sizes)} rows exceeds capacity {cap}")
-            idx = torch.cat(batches) if n > 1 else batches[0].contiguous()
+            idx = torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
+            if idx.numel() != sum(sizes):
+                raise UmlhError("train_steps: index slices do not match their batch sizes")
             offs = (C.c_int32 * (n + 1))()
             acc = 0
             for k, sz in enumerate(sizes):
@@ -215,9 +232,16 @@ class HeadEngine:
         si, keep_i = stream(img_table, img_index_batches, self.d_img, self.cfg.max_rows_img)
         st, keep_t = stream(txt_table, txt_index_batches, self.d_shared, self.cfg.max_rows_txt)
         lr_arr = (C.c_double * n)(*[float(x) for x in lrs])
-        check(self.lib.umlh_train_steps(self.handle, self._ref(si), self._ref(st), n, lr_arr, int(first_step),
-                                        float(alpha), float(img_alpha), _ptr(scalars_out), self._stream()),
-              "umlh_train_steps")
+        lock = ENQUEUE_LOCK
+        if lock is not None:
+            lock.acquire()
+        try:
+            rc = self.lib.umlh_train_steps(self.handle, self._ref(si), self._ref(st), n, lr_arr, int(first_step),
+                                           float(alpha), float(img_alpha), _ptr(scalars_out), self._stream())
+        finally:
+            if lock is not None:
+                lock.release()
+        check(rc, "umlh_train_steps")
         # index tensors must outlive the enqueued kernels: keep them until the next call
         self._keepalive = (keep_i, keep_t)
 
