@@ -146,3 +146,14 @@ def test_model_surface_and_seed_parity_of_init():
         UML(8, 0, 3, bias=True)
     with pytest.raises(ValueError):
         UML("vit_base_patch16_224", 0, 3)
+
+
+def test_host_cpu_budget_and_thread_fit():
+    """umlh fits torch's intra-op pool to the CPUs the process may really use (affinity and cgroup quota)."""
+    import os
+    import torch
+    import umlh
+    b = umlh.host_cpu_budget()
+    assert 1 <= b <= (os.cpu_count() or 1)
+    if "OMP_NUM_THREADS" not in os.environ:
+        assert torch.get_num_threads() <= b
