@@ -150,18 +150,17 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     // (64 cycles per 32x32x2) is what bounds a single-workgroup forward, and its SIMD partner then
     // runs alone.  Wave-uniform; the accumulators stay 0 and the epilogue masks them as before.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const bool rows_live = row0 + (wave_u / WC) * 32 < sg.rows;
+    const bool wave_live = row0 + (wave_u / WC) * 32 < sg.rows && (wave_u % WC) * CTW * 32 < C;
     auto compute = [&](int buf) {
         const float* Ws = Ws0 + buf * BUF;
         const float* Xs = Ws + KT * LDW;
-        if (!rows_live) return;
+        if (!wave_live) return;                       // ONE wave-uniform branch per chunk: the MFMA loop itself stays branch-free
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
             const int krow = 2 * kk + h;
             const float b = Xs[krow * LDX + ws * 32 + l31];
 #pragma unroll
             for (int ct = 0; ct < CTW; ++ct) {
-                if (((wave_u % WC) * CTW + ct) * 32 >= C) continue;
                 const float av = Ws[krow * LDW + (wc * CTW + ct) * 32 + l31];
                 acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[ct], 0, 0, 0);
             }
