@@ -240,3 +240,39 @@ def test_bf16_training_accuracy_parity_with_fp32():
     print(f"top-1 fp32 {accs['fp32']:.4f}  bf16 {accs['bf16']:.4f}  diff {100 * (accs['bf16'] - accs['fp32']):+.3f} pp")
     assert accs["fp32"] > 0.5
     assert abs(accs["bf16"] - accs["fp32"]) <= 0.0025
+
+
+def test_bf16_two_layer_head_split_step_equals_fused_step():
+    """Data-parallel split (grad_step -> apply_update) == fused train_step for the bf16 2-layer head: same weights,
+    optimizer state and scalars after 3 steps (single rank: the all-reduce is the identity)."""
+    import umlh
+    rng = np.random.default_rng(9)
+    d_img, d_sh, C, n, B = 128, 128, 20, 500, 96
+    xi = rng.standard_normal((n, d_img)).astype(np.float32)
+    xt = rng.standard_normal((n, d_sh)).astype(np.float32)
+    yi, yt = rng.integers(0, C, n), rng.integers(0, C, n)
+    wp = (rng.standard_normal((d_sh, d_img)) / np.sqrt(d_img)).astype(np.float32)
+    wh = (0.1 * rng.standard_normal((C, d_sh))).astype(np.float32)
+    T = lambda a, t=torch.float32: torch.as_tensor(a).to(DEV, t).contiguous()
+    Xi, Yi, Xt, Yt = T(xi), T(yi, torch.int64), T(xt), T(yt, torch.int64)
+    Xi16, Xt16 = umlh.to_bf16(Xi), umlh.to_bf16(Xt)
+    engines = []
+    for _ in range(2):
+        e = umlh.HeadEngine(d_img, d_sh, C, has_proj=True, learnable_temp=True, optimizer="adamw", weight_decay=0.01,
+                            max_rows_img=B, max_rows_txt=B, precision="bf16", device=DEV)
+        e.w_head.copy_(T(wh)); e.w_proj.copy_(T(wp)); e.scales.fill_(5.0)
+        engines.append(e)
+    g = torch.Generator().manual_seed(1)
+    for step in range(1, 4):
+        ii = torch.randint(0, n, (B,), generator=g).to(DEV)
+        ti = torch.randint(0, n, (70,), generator=g).to(DEV)
+        bi = umlh.RowBatch(Xi, Yi, ii, feats_bf16=Xi16)
+        bt = umlh.RowBatch(Xt, Yt, ti, feats_bf16=Xt16)
+        s1 = engines[0].train_step(bi, bt, lr=2e-3, step=step, alpha=0.5).clone()
+        engines[1].grad_step(bi, bt, alpha=0.5)
+        s2 = engines[1].apply_update(lr=2e-3, step=step).clone()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(s1[:8].cpu().numpy(), s2[:8].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for name in ("w_head", "w_proj", "m_head", "v_head", "m_proj", "v_proj", "scales"):
+        a, b = getattr(engines[0], name).cpu().numpy(), getattr(engines[1], name).cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=name)
