@@ -111,3 +111,18 @@ def test_alternation_loop_trajectory_matches_reference(tag):
     np.testing.assert_allclose(r["loss"], ref[:, 2], atol=5e-4)
     np.testing.assert_allclose(m.decoders[0].fc.weight.detach().cpu().numpy(), g["traj_dec0_w"], atol=3e-4)
     np.testing.assert_allclose(m.xproj_in.fc.weight.detach().cpu().numpy(), g["traj_xproj_w"], atol=3e-4)
+
+
+def test_get_embedding_is_time_mean_of_encoder_outputs():
+    from multibench.models import UML, Linear, Transformer
+    torch.manual_seed(0)
+    z = 20
+    enc = Transformer(z, z, nhead=5, num_layers=1, conv1d=True, out_last=False, pos_embd=True, pos_learnable=False, max_len=128)
+    m = UML(Linear(7, z), Linear(9, z), enc, [Linear(z, 7), Linear(z, 9)]).to(DEV).eval()
+    x, y = torch.randn(4, 11, 7, device=DEV), torch.randn(4, 11, 9, device=DEV)
+    ex, ey = m.get_embedding(x, y)
+    with torch.no_grad():
+        rx = m.encoder(m.xproj_in(x)).mean(dim=1)
+        ry = m.encoder(m.yproj_in(y)).mean(dim=1)
+    np.testing.assert_allclose(ex.cpu().numpy(), rx.cpu().numpy(), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(ey.cpu().numpy(), ry.cpu().numpy(), atol=1e-6, rtol=1e-5)

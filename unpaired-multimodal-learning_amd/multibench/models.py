@@ -193,6 +193,20 @@ class UML(nn.Module):
                 "diff_next_x": diff_next_x, "diff_next_y": diff_next_y}
 
     def get_embedding(self, x, y):
+        """Time-averaged encoder outputs (models.py:273-277); the mean over the sequence runs on the HIP reduction
+        (``umlh_positions_backward`` sums the middle dimension of a [B,T,Z] block)."""
         x = x.unsqueeze(1).float() if x.ndim == 2 else x
         y = y.unsqueeze(1).float() if y.ndim == 2 else y
-        return self.encoder(self.xproj_in(x)).mean(dim=1), self.encoder(self.yproj_in(y)).mean(dim=1)
+        return self._time_mean(self.encoder(self.xproj_in(x))), self._time_mean(self.encoder(self.yproj_in(y)))
+
+    @staticmethod
+    def _time_mean(h):
+        import umlh
+        from umlh._lib import check
+        h = h.detach().to(torch.float32).contiguous()
+        B, T, Z = h.shape
+        out = torch.empty(B, Z, dtype=torch.float32, device=h.device)
+        st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        check(umlh.load_library().umlh_positions_backward(C.c_void_p(h.data_ptr()), B, T, Z, C.c_void_p(out.data_ptr()), st),
+              "umlh_positions_backward")
+        return out / T
