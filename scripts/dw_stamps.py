@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase cycle stamps of dw_bf16 (UMLH_DBG_DW=16+ablation bits; argv[1] = bits:
-1 = no dZ^T traffic, 2 = no feature traffic)."""
+1 = no dZ^T traffic, 2 = no feature traffic; the bits need a library built with UMLH_BUILD_ABLATIONS=1)."""
 import ctypes as C
 import os
 import sys

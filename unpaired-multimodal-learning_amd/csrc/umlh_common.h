@@ -81,7 +81,7 @@ struct FwdArgsB {
     u16*  dzt;                   // bf16 dZ^T, column-chunk-major [cols/64][crows][64]; NULL = eval
     int   crows;                 // class rows per column chunk (C rounded up to 128)
     float* partials;
-    int   dbg;                   // timing-only ablations: 1 = main loop only, 2 = epilogue only
+    int   dbg;                   // 9 = cycle stamps; other values: timing-only ablations (analysis build -DUMLH_ABLATIONS only)
     int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
     unsigned long long* stamps;  // diagnostic build only (UMLH_DBG_FWD=9): [grid][8] s_memtime stamps of wave 0
     float* diag_zero;            // 4 floats zeroed by block 0 (gradient-diagnostic accumulators of this step), or NULL
@@ -98,7 +98,7 @@ struct DwArgsB {
     const u16* B2; const int64_t* k_rows2; int ldb2;    // text-side feature rows (k >= k_switch)
     float* out;                  // fp32 slabs [splits][M][ldo]
     const u16* zeros;            // >= 16 B of zeros (source of masked loads)
-    int   dbg;                   // timing-only ablations: bit0 = no A traffic, bit1 = no F traffic
+    int   dbg;                   // timing-only ablations, analysis build -DUMLH_ABLATIONS only: bit0 = no A traffic, bit1 = no F traffic, bit2 = no main loop
     int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit;
     int   nsplit1;               // slabs [0, nsplit1) cover k in [0, k_switch), the rest [k_switch, K): k_chunk rows each
     const int64_t* a_rows;       // AM 1: row ids of A (never NULL: identity table for dense operands)

@@ -11,6 +11,15 @@
 #include "umlh_common.h"
 #include <type_traits>
 
+// Timing-only ablations (skip the main loop / the epilogue / an operand's traffic) exist for kernel analysis and are
+// compiled in only with -DUMLH_ABLATIONS: the shipped library has no path that skips work.  The cycle stamps
+// (UMLH_DBG_FWD=9, UMLH_DBG_DW=16) do not change what is computed and stay available.
+#ifdef UMLH_ABLATIONS
+#define UMLH_ABL(cond) (cond)
+#else
+#define UMLH_ABL(cond) (false)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     }
 
     STAMP(1);
-    for (int kb0 = 0; kb0 < ((a.dbg == 2 || a.dbg == 5) ? 0 : K); kb0 += XK) {
+    for (int kb0 = 0; kb0 < (UMLH_ABL(a.dbg == 2 || a.dbg == 5) ? 0 : K); kb0 += XK) {
         const int kbw = min(XK, K - kb0);                        // multiple of 128
         // ---- stage the X block: global -> registers -> LDS ----
         u32x4 xr[NPX];
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     }
 
     STAMP(2);
-    if (a.dbg == 1 || a.dbg == 5) {                    // ablation: keep the accumulators live, skip the epilogue
+    if (UMLH_ABL(a.dbg == 1 || a.dbg == 5)) {          // ablation: keep the accumulators live, skip the epilogue
         float t = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct)
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         }
         rawy += __shfl_xor(rawy, 32);                    // both lanes of the sample: label logit or 0
         STAMP(6);
-        if (a.dbg == 4) { bl += mk + rawy; continue; }   // ablation: max + label passes only
+        if (UMLH_ABL(a.dbg == 4)) { bl += mk + rawy; continue; }   // ablation: max + label passes only
         // ---- pass 2: first arg-max, e = exp(z - WAVE-LOCAL max), sums.  The waves' partial results are
         // merged afterwards with the online-softmax rule (one LDS exchange instead of max-then-sum) ----
         // wave-local max scaled logit, in log2 units.  A wave whose classes are ALL padding has
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         STAMP(3);
         const float zy = rawy * ascale;                  // (sgn*raw_y) * |scale| = scale * raw_y
         // ---- pass 3: dZ^T (bf16) ----
-        if (a.dzt != nullptr && a.dbg != 3 && a.dbg != 4) {
+        if (a.dzt != nullptr && !UMLH_ABL(a.dbg == 3 || a.dbg == 4)) {
             const float coef = valid ? sg.w_over_rows * scale : 0.f;
             const float ic = coef * fown * __builtin_amdgcn_rcpf(se);   // dZ = e_local * exp(m_wave - m) / S * coef - onehot*coef
             if (WC == 1 && st == 0) __syncthreads();       // staging aliases the X tile: every wave must have left the main loop
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
         const size_t achunk = AM == 0 ? (size_t)(k0 >> 6) * g.lda * 64 : (size_t)k0;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const u16* ap = (k0 + a_col[q] < ke && !(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
+            const u16* ap = (k0 + a_col[q] < ke && !UMLH_ABL(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
             sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
         }
     };
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int rid = ids[c * DKT + f_row[q]];
-            const u16* fp = (rid != DMASK && f_colok[q] && !(g.dbg & 2)) ? fb + (size_t)rid * ld + f_col[q] : g.zeros;
+            const u16* fp = (rid != DMASK && f_colok[q] && !UMLH_ABL(g.dbg & 2)) ? fb + (size_t)rid * ld + f_col[q] : g.zeros;
             sg.f[q] = *reinterpret_cast<const u32x4*>(fp);
         }
     };
@@ -674,18 +683,18 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
         const int k0 = kb + c * DKT;
         if (pc < 2) {
             const size_t achunk = AM == 0 ? (size_t)(k0 >> 6) * g.lda * 64 : (size_t)k0;
-            const u16* ap = (k0 + a_col[q] < ke && !(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
+            const u16* ap = (k0 + a_col[q] < ke && !UMLH_ABL(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
             sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
         } else {
             const bool seg2 = k0 >= g.k_switch;
             const u16* fb = seg2 ? g.B2 : g.B;
             const int ld = seg2 ? g.ldb2 : g.ldb;
             const int rid = rids[q];
-            const u16* fp = (rid != DMASK && f_colok[q] && !(g.dbg & 2)) ? fb + (size_t)rid * ld + f_col[q] : g.zeros;
+            const u16* fp = (rid != DMASK && f_colok[q] && !UMLH_ABL(g.dbg & 2)) ? fb + (size_t)rid * ld + f_col[q] : g.zeros;
             sg.f[q] = *reinterpret_cast<const u32x4*>(fp);
         }
     };
-    for (int c = 0; c < ((g.dbg & 4) ? 0 : nchunks); c += DNS) {      // dbg bit2: skip the main loop (fixed-cost probe)
+    for (int c = 0; c < (UMLH_ABL(g.dbg & 4) ? 0 : nchunks); c += DNS) {      // dbg bit2: skip the main loop (fixed-cost probe)
 #pragma unroll
         for (int d = 0; d < DNS; ++d) {
             const int nd = (d + 1) % DNS;

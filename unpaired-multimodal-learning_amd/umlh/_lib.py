@@ -79,6 +79,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I", _INCLUDE, "-I", _CSRC, *srcs, "-o", _SO + ".tmp"]
+    if os.environ.get("UMLH_BUILD_ABLATIONS") == "1":     # kernel-analysis build: timing-only work-skipping switches
+        cmd.insert(1, "-DUMLH_ABLATIONS")
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
