@@ -804,8 +804,8 @@ int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStrea
     if (g->M <= 0 || g->N <= 0) return 0;
     // 64x64 tiles when the 128x128 grid would leave most of the 256 CUs with a single 4-wave workgroup
     long long wg128 = (long long)((g->N + 127) / 128) * ((g->M + 127) / 128) * splits;
-    const char* e = getenv("UMLH_F32_TM");
-    const int tm = e ? atoi(e) : (wg128 < 768 ? 1 : 2);
+    static const int tm_env = [] { const char* e = getenv("UMLH_F32_TM"); return e ? atoi(e) : 0; }();   // tile override for tuning runs
+    const int tm = (tm_env == 1 || tm_env == 2) ? tm_env : (wg128 < 768 ? 1 : 2);
     const int t = 64 * tm;
     dim3 grid((g->N + t - 1) / t, (g->M + t - 1) / t, splits);
 #define GEMM_CASE(A_, B_, T_) if (ta == A_ && tb == B_ && tm == T_) { hipLaunchKernelGGL((gemm_f32<A_, B_, T_>), grid, dim3(256), 0, stream, *g); return (int)hipGetLastError(); }
