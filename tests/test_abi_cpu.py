@@ -49,3 +49,17 @@ def test_no_gpu_is_a_loud_error():
         pytest.skip("GPU present")
     with pytest.raises(umlh.UmlhError):
         umlh.HeadEngine(8, 8, 4, device="cpu")
+
+
+def test_encoder_ops_validate_arguments_before_touching_the_gpu(lib):
+    """The MultiBench encoder ops reject bad arguments with a message (no HIP call is made on these paths)."""
+    fake = C.c_void_p(64)                                   # never dereferenced: the shape checks come first
+    assert lib.umlh_gemm_f32(None, None, None, 4, 4, 4, 4, 4, 4, 0, 0, None, None, C.c_float(1.0), 1, None, None) != 0
+    assert b"umlh_gemm_f32" in lib.umlh_last_error()
+    assert lib.umlh_gemm_f32(fake, fake, fake, 4, 4, 4, 4, 4, 4, 0, 0, None, None, C.c_float(1.0), 3, None, None) != 0   # splits without slabs
+    rc = lib.umlh_attention_forward(fake, None, 200, 2, 20, 5, C.c_float(0.0), C.c_uint64(0), fake, fake, None)
+    assert rc != 0 and b"envelope" in lib.umlh_last_error()
+    rc = lib.umlh_attention_backward(fake, None, fake, fake, 16, 2, 330, 5, C.c_float(0.0), C.c_uint64(0), fake, None)   # head dim 66
+    assert rc != 0 and b"envelope" in lib.umlh_last_error()
+    assert lib.umlh_dropout(fake, 10, C.c_float(1.5), C.c_uint64(1), None) != 0
+    assert lib.umlh_eval_rows(None, None, None, None) != 0
