@@ -686,21 +686,38 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
 }
 
 // --------------------------------------------------------------------------- //
-// zero-shot head init: one block per class, rows visited in index order
+// zero-shot head init: one block per class, rows accumulated in index order.  The labels are scanned 256 at a time
+// (every thread looking at ALL n labels cost 2.8 ms at ImageNet's 29 940 text rows); the matches of a window are
+// compacted in row order (wave ballot + prefix), so each column still adds its rows in ascending order -- the
+// result is bit-identical to the serial scan.
 // --------------------------------------------------------------------------- //
 __global__ __launch_bounds__(256) void zero_shot_kernel(const float* __restrict__ feats,
                                                         const int64_t* __restrict__ labels, long long n, int d,
                                                         float* __restrict__ w) {
     extern __shared__ float zsum[];          // [d] + [256]
+    __shared__ int midx[256];
+    __shared__ int wcnt[4];
     float* redn = zsum + d;
-    const int c = blockIdx.x, tid = threadIdx.x;
-    for (int j = tid; j < d; j += 256) zsum[j] = 0.f;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int j = tid; j < d; j += 256) zsum[j] = 0.f;            // column j is owned by thread j % 256 throughout
     int count = 0;
-    for (long long r = 0; r < n; ++r) {
-        if (labels[r] == c) {
-            ++count;
-            for (int j = tid; j < d; j += 256) zsum[j] += feats[(size_t)r * d + j];
+    for (long long base = 0; base < n; base += 256) {
+        const long long r = base + tid;
+        const bool hit = r < n && labels[r] == c;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int k = 0; k < wv; ++k) off += wcnt[k];
+        const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        if (hit) midx[off + __popcll(bal & ((1ULL << lane) - 1ULL))] = tid;
+        __syncthreads();
+        for (int q = 0; q < total; ++q) {
+            const float* row = feats + (size_t)(base + midx[q]) * d;
+            for (int j = tid; j < d; j += 256) zsum[j] += row[j];
         }
+        count += total;
+        __syncthreads();                                          // midx / wcnt are rewritten by the next window
     }
     float ss = 0.f;
     for (int j = tid; j < d; j += 256) {
