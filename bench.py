@@ -173,8 +173,14 @@ def main():
                 acc[name] = acc.get(name, 0.0) + ms / nprof
         engine.profile(False)
         flops = {"fwd_ce": 2.0 * 2 * BATCH * C * D, "dw_head": 2.0 * 2 * BATCH * C * D}   # algorithmic, per launch
-        dom = max(("fwd_ce", "dw_head"), key=lambda n: acc[n])
-        achieved = flops[dom] / (acc[dom] * 1e-3) / 1e12
+        # Every event interval carries the cost of its marker packets: the five intervals of a step sum to more than
+        # the un-instrumented step measured above (66.9 vs 49.3 us at cfg2; the two intervals that contain NO kernel
+        # for the linear head read 5-8 us).  That excess, spread evenly, is taken off each interval; the calibrated
+        # kernel time is what agrees with rocprofv3's kernel trace (profiles/r01_kernel_stats.md).
+        ev_over = max(0.0, (sum(acc.values()) - dt / steps * 1e3) / len(acc))
+        cal = {k: max(v - ev_over, 0.0) for k, v in acc.items()}
+        dom = max(("fwd_ce", "dw_head"), key=lambda n: cal[n])
+        achieved = flops[dom] / (cal[dom] * 1e-3) / 1e12
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file's note)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bf16_pmc.json")))["kernels"]
@@ -184,7 +190,8 @@ def main():
             traffic = None
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[precision],
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK[precision], 4), "traffic": traffic,
-                "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
+                "kernel_ms": {k: round(v, 4) for k, v in cal.items()},
+                "event_interval_ms_raw": {k: round(v, 4) for k, v in acc.items()}, "event_overhead_ms_per_interval": round(ev_over, 4),
                 "step_frac_of_mfma_roof": round((sum(flops.values()) / (PEAK[precision] * 1e12)) / (dt / steps), 4)}
         return {"value": rows / dt, "dt": dt, "rows": rows, "ms_per_step": dt / steps * 1e3,
                 "host_enqueue_ms_per_step": t_enq / steps * 1e3, "final": final, "roofline": roof}
