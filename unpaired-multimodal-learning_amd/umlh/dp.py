@@ -8,7 +8,7 @@ concatenation of all ranks' rows -- every rank divides its partial gradient and 
 partial loss sums by the GLOBAL row counts before the all-reduce
 (``RowBatch.global_rows``), so SUM over ranks is the global mean.
 
-Message: [g_head | g_proj | g_scales(2) | scalars(8)] fp32 -- 2.05 MB for the
+Message: [g_head | g_proj | g_scales(2) | scalars(12)] fp32 -- 2.05 MB for the
 ImageNet CLIP-B/16 head (C=1000, d=512), one bucket, one collective.
 """
 from __future__ import annotations
