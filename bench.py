@@ -40,8 +40,8 @@ def synth_rows(n, d, c, seed, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--precision", default=os.environ.get("UMLH_PRECISION", "bf16"), choices=["fp32", "bf16"],
                     help="bf16 = BASELINE config 2 (headline); fp32 = exact-parity mode")
     ap.add_argument("--force-dp-path", action="store_true", help="N=1 only: run the data-parallel split path (grad_step -> [all_reduce] -> apply_update, per-step host loop) to price it")
