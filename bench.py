@@ -10,10 +10,24 @@ softmax-CE forward, dW, AdamW), workload = BASELINE config 2 (ImageNet-1k, CLIP 
 features d=512, C=1000, unpaired CUPL text).  Inputs are synthetic, resident in HBM
 before the timed region.  N>1: plain data parallel, one RCCL all-reduce of the head
 gradient per step, weak scaling.  Rank 0 prints ONE JSON line.
+
+Launched without a rendezvous environment (`python bench.py --gpus N`, N > 1) the script
+starts its own N ranks as a `torch.distributed.run` child BEFORE anything touches the GPU
+and exits with the child's code.
+
+Timing: after `--prime` untimed steps (clocks, caches, allocator) and the W warm-up steps, the
+block of EXACTLY K steps is timed `--repeats` times, each bracketed by barrier + synchronize on
+both sides; `value` / `ms_per_step` are the MEDIAN block (all blocks are listed in
+`block_ms_per_step`).  A single 20-step block is 1 ms of device work: its time is mostly the
+fences and the launch ramp, which is why the median of many blocks is reported.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -21,15 +35,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "unpaired-multimodal-learning_amd"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 METRIC = "samples/sec (img+text feats) UML head fine-tune, batch 4096, 1/2/4/8 GPU"
 N_IMG, N_TXT, D, C, BATCH = 1_281_167, 29_940, 512, 1000, 4096
 PEAK = {"fp32": 157.3, "bf16": 2500.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+L2_BW = 34.5e12                              # aggregate L2 -> CU bandwidth, MI355X_MICROARCH.md "L2 (per XCD)"
 
 
-def synth_rows(n, d, c, seed, device):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=0, help="timed K-step blocks (0 = auto: about 3000 steps in all, 3..50 blocks)")
+    ap.add_argument("--prime", type=int, default=300, help="untimed steps before the warm-up (clock ramp, caches)")
+    ap.add_argument("--precision", default=os.environ.get("UMLH_PRECISION", "bf16"), choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE config 2 (headline); fp32 = exact-parity mode")
+    ap.add_argument("--force-dp-path", action="store_true", help="N=1 only: run the data-parallel split path (grad -> [all-reduce] -> update) to price it")
+    ap.add_argument("--dp-host-loop", action="store_true", help="N>1: per-step Python stepping (torch.distributed all_reduce) instead of the C-level RCCL loop")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the additional fp32 parity-mode measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order-rng", default="device", choices=["device", "torch-cpu"],
+                    help="epoch permutations drawn on the GPU (default) or by the reference-identical CPU sampler")
+    ap.add_argument("--block", type=int, default=25, help="steps per umlh_train_steps call (host prepares the next block meanwhile)")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a rendezvous environment: run N ranks as a child
+    `torch.distributed.run` (fresh processes: nothing in THIS process has touched the GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def synth_rows(torch, n, d, c, seed, device):
     g = torch.Generator(device=device).manual_seed(seed)
     x = torch.randn(n, d, generator=g, device=device, dtype=torch.float32)
     x = torch.nn.functional.normalize(x, dim=1)
@@ -37,25 +83,30 @@ def synth_rows(n, d, c, seed, device):
     return x, y
 
 
+def latest_pmc():
+    """HBM bytes per launch from the newest committed PMC summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes; see
+    the file's note).  STATIC: collected by scripts/profile_round.sh, not in this run."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bf16_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1]))["kernels"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--precision", default=os.environ.get("UMLH_PRECISION", "bf16"), choices=["fp32", "bf16"],
-                    help="bf16 = BASELINE config 2 (headline); fp32 = exact-parity mode")
-    ap.add_argument("--force-dp-path", action="store_true", help="N=1 only: run the data-parallel split path (grad_step -> [all_reduce] -> apply_update, per-step host loop) to price it")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the additional fp32 parity-mode measurement")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--order-rng", default="device", choices=["device", "torch-cpu"],
-                    help="epoch permutations drawn on the GPU (default) or by the reference-identical CPU sampler")
-    ap.add_argument("--block", type=int, default=25, help="steps per umlh_train_steps call (host prepares the next block meanwhile)")
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
     # one rank per GPU (RCCL over xGMI).  Rehearsal on a box with fewer GPUs than ranks: ranks share GPUs and the
@@ -63,12 +114,16 @@ def main():
     rehearsal = world > n_dev
     dev = torch.device("cuda", local % max(1, n_dev))
     torch.cuda.set_device(dev)
+    rccl_ranks = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+            rccl_ranks = dist.get_world_size()
+            if rccl_ranks != args.gpus:
+                raise SystemExit(f"RCCL world size {rccl_ranks} != --gpus {args.gpus}")
 
     import umlh
     from engine.datasets.utils import FeatureLoader, FeatureTable
@@ -78,11 +133,13 @@ def main():
     from engine.tools.utils import set_random_seed
     from finetune import _RowSource
 
+    repeats = args.repeats if args.repeats > 0 else max(3, min(50, -(-3000 // max(1, args.steps))))
+
     # ---- synthetic, HBM-resident workload (image rows sharded over ranks, text replicated) ----
     set_random_seed(0)
     n_img_local = (N_IMG + world - 1) // world
-    x_img, y_img = synth_rows(n_img_local, D, C, 100 + rank, dev)
-    x_txt, y_txt = synth_rows(N_TXT, D, C, 7, dev)
+    x_img, y_img = synth_rows(torch, n_img_local, D, C, 100 + rank, dev)
+    x_txt, y_txt = synth_rows(torch, N_TXT, D, C, 7, dev)
     model = UMLClip(D, C, logit_scale_init=4.60517).to(dev)            # s = 100 (config/__init__.py:209-216)
     model.zero_shot_init(FeatureTableAsText(x_txt, y_txt))
     optimizer = build_optimizer(model.parameters(), "adamw", 1e-3, 0.01)
@@ -92,8 +149,10 @@ def main():
                                        order_rng=args.order_rng), dev, "image", args.precision)
     txt_src = _RowSource(FeatureLoader(FeatureTable(x_txt, y_txt, dev), BATCH, shuffle=True, kind="text",
                                        order_rng=args.order_rng), dev, "text", args.precision)
-    scal = torch.zeros(2 * (args.warmup + args.steps) + 128, umlh.N_SCALARS, device=dev)
+    ring = 4096                                                          # per-step scalar rows (device ring)
+    scal = torch.zeros(ring, umlh.N_SCALARS, device=dev)
     cursor = {"k": 0}
+    dp_path = world > 1 or args.force_dp_path
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -101,35 +160,44 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def measure(precision, steps, warmup):
-        """W warm-up steps, then `steps` timed steps bracketed by barrier + synchronize."""
+    def measure(precision, steps, warmup, prime):
+        """`prime` + `warmup` untimed steps, then `repeats` timed blocks of `steps` steps, each bracketed by
+        barrier + synchronize; returns the median block."""
         engine = model.fused_engine(optimizer, BATCH, BATCH, precision=precision)
         stepper = umlh.DataParallelStepper(engine)
         stepper.broadcast_parameters([model.head.weight.data])
         tab_i, tab_t = img_src.table(precision), txt_src.table(precision)
-
         engine.bind_tables(tab_i, tab_t)
+        c_level_dp = world > 1 and not rehearsal and not args.dp_host_loop and stepper.attach_rccl()
+
+        def slot(m):
+            if cursor["k"] + m > ring:
+                cursor["k"] = 0
+            k = cursor["k"]
+            cursor["k"] += m
+            return scal[k:k + m]
 
         def one_step():
             ii, ti = img_src.next_index(), txt_src.next_index()
-            if world > 1 or args.force_dp_path:       # grad -> all-reduce -> update, lean host path
+            out = slot(1)[0]
+            if dp_path:       # grad -> all-reduce -> update, lean host path
                 stepper.step_indexed(ii, ti, lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1,
-                                     alpha=1.0, scalars_out=scal[cursor["k"]])
+                                     alpha=1.0, scalars_out=out)
             else:
                 engine.train_step(umlh.RowBatch(tab_i[0], tab_i[1], ii, feats_bf16=tab_i[2] if len(tab_i) > 2 else None),
                                   umlh.RowBatch(tab_t[0], tab_t[1], ti, feats_bf16=tab_t[2] if len(tab_t) > 2 else None),
                                   lr=optimizer.param_groups[0]["lr"], step=optimizer.step_count + 1, alpha=1.0,
-                                  scalars_out=scal[cursor["k"]])
-            cursor["k"] += 1
+                                  scalars_out=out)
             optimizer.step_count += 1
             scheduler.step()
             return int(ii.numel()) + int(ti.numel())
 
         def run_steps(n):
-            """N=1: blocks of `--block` steps through ONE umlh_train_steps call each (the host prepares
-            the next block's index vectors while the GPU runs); N>1: per-step DP stepping."""
+            """Blocks of `--block` steps through ONE umlh_train_steps call each (the host prepares the next block's
+            index vectors while the GPU runs) -- with a communicator attached the same call also runs the
+            data-parallel step (grad -> ncclAllReduce -> update, all enqueued from C); otherwise N>1 steps from Python."""
             rows = 0
-            if world > 1 or args.force_dp_path:
+            if dp_path and not c_level_dp:
                 for _ in range(n):
                     rows += one_step()
                 return rows
@@ -141,67 +209,77 @@ def main():
                     bi.append(img_src.next_index())
                     bt.append(txt_src.next_index())
                 engine.train_steps(tab_i, bi, tab_t, bt, scheduler.lr_table(m), first_step=optimizer.step_count + 1,
-                                   alpha=1.0, scalars_out=scal[cursor["k"]:cursor["k"] + m])
-                cursor["k"] += m
+                                   alpha=1.0, scalars_out=slot(m))
                 optimizer.step_count += m
                 scheduler.step(scheduler.last_epoch + m)
                 rows += sum(int(b.numel()) for b in bi) + sum(int(b.numel()) for b in bt)
                 done += m
             return rows
 
+        run_steps(prime)
         run_steps(warmup)
-        fence()
-        t0 = time.perf_counter()
-        rows = run_steps(steps)
-        t_enq = time.perf_counter() - t0
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-            r = torch.tensor([rows], device=dev, dtype=torch.float64)
-            dist.all_reduce(r, op=dist.ReduceOp.SUM)
-            rows = int(r.item())
+        blocks, enq = [], []
+        for _ in range(repeats):
+            fence()
+            t0 = time.perf_counter()
+            rows = run_steps(steps)
+            t_enq = time.perf_counter() - t0
+            fence()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt, rows], device=dev, dtype=torch.float64)
+                tm = t.clone()
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                dt, rows = float(tm[0].item()), int(t[1].item())
+            blocks.append((dt, rows))
+            enq.append(t_enq)
+        order = sorted(range(repeats), key=lambda i: blocks[i][0])
+        med = order[(repeats - 1) // 2]                 # the median block itself (lower median: a measured block)
+        dt, rows = blocks[med]
         final = scal[cursor["k"] - 1].cpu().tolist()
-        # roofline leg: per-kernel device time from HIP events recorded on the step's stream
+        # roofline leg: per-kernel device time from HIP events recorded on the step's stream (RAW intervals: each
+        # carries the cost of its two marker packets, so they read a few hundred ns above rocprofv3's kernel trace)
         engine.profile(True)
-        acc, nprof = {}, 30
+        acc, nprof = {}, 50
         for _ in range(nprof):
             one_step()
             for name, ms in engine.profile_read().items():
                 acc[name] = acc.get(name, 0.0) + ms / nprof
         engine.profile(False)
         flops = {"fwd_ce": 2.0 * 2 * BATCH * C * D, "dw_head": 2.0 * 2 * BATCH * C * D}   # algorithmic, per launch
-        # Every event interval carries the cost of its marker packets: the five intervals of a step sum to more than
-        # the un-instrumented step measured above (66.9 vs 49.3 us at cfg2; the two intervals that contain NO kernel
-        # for the linear head read 5-8 us).  That excess, spread evenly, is taken off each interval; the calibrated
-        # kernel time is what agrees with rocprofv3's kernel trace (profiles/r01_kernel_stats.md).
-        ev_over = max(0.0, (sum(acc.values()) - dt / steps * 1e3) / len(acc))
-        cal = {k: max(v - ev_over, 0.0) for k, v in acc.items()}
-        dom = max(("fwd_ce", "dw_head"), key=lambda n: cal[n])
-        achieved = flops[dom] / (cal[dom] * 1e-3) / 1e12
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file's note)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bf16_pmc.json")))["kernels"]
-            if precision == "bf16":
-                traffic = pmc[{"fwd_ce": "fwd_ce_bf16", "dw_head": "dw_bf16"}[dom]]["hbm_bytes_corrected"]
-        except Exception:
-            traffic = None
+        dom = max(("fwd_ce", "dw_head"), key=lambda n: acc[n])
+        achieved = flops[dom] / (acc[dom] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[precision],
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK[precision], 4), "traffic": traffic,
-                "kernel_ms": {k: round(v, 4) for k, v in cal.items()},
-                "event_interval_ms_raw": {k: round(v, 4) for k, v in acc.items()}, "event_overhead_ms_per_interval": round(ev_over, 4),
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK[precision], 4), "traffic": None,
+                "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
+                "kernel_ms_source": "HIP events on the step's stream, raw intervals, mean of %d instrumented steps" % nprof,
                 "step_frac_of_mfma_roof": round((sum(flops.values()) / (PEAK[precision] * 1e12)) / (dt / steps), 4)}
+        if precision == "bf16":
+            pmc, src = latest_pmc()
+            key = {"fwd_ce": "fwd_ce_bf16", "dw_head": "dw_bf16"}[dom]
+            if pmc and key in pmc:
+                roof["traffic"] = pmc[key].get("hbm_bytes_corrected")
+                roof["traffic_source"] = f"static: {src} (rocprofv3 --pmc passes, not collected in this run)"
+            # second roof of the forward's present decomposition: every CU streams all of W from L2 for its 32 rows
+            l2_bytes = (8192 / 32) * 1024 * 512 * 2
+            roof["l2_stream_bound_ms"] = round(l2_bytes / L2_BW * 1e3, 5)
         return {"value": rows / dt, "dt": dt, "rows": rows, "ms_per_step": dt / steps * 1e3,
-                "host_enqueue_ms_per_step": t_enq / steps * 1e3, "final": final, "roofline": roof}
+                "block_ms_per_step": [round(b[0] / steps * 1e3, 4) for b in blocks],
+                "host_enqueue_ms_per_step": statistics.median(enq) / steps * 1e3, "final": final, "roofline": roof,
+                "c_level_dp": bool(c_level_dp)}
 
-    head = measure(args.precision, args.steps, args.warmup)
+    head = measure(args.precision, args.steps, args.warmup, args.prime)
     other = None
     if args.precision == "bf16" and not args.no_fp32_leg:
-        # the exact-parity fp32 mode on the same workload (fewer steps: it is ~4x slower)
-        other = measure("fp32", max(10, args.steps // 4), max(3, args.warmup // 4))
-    value, dt, roofline, final = head["value"], head["dt"], head["roofline"], head["final"]
+        # the exact-parity fp32 mode on the same workload (fewer steps: it is ~5x slower)
+        other = measure("fp32", max(10, args.steps // 4), max(3, args.warmup // 4), max(10, args.prime // 4))
+    value, roofline, final = head["value"], head["roofline"], head["final"]
+    if other is not None:   # the parity mode's figures as scalars next to the headline's (1e-4 logits/loss parity lives here)
+        roofline.update({"fp32_value": round(other["value"], 1), "fp32_ms_per_step": round(other["ms_per_step"], 4),
+                         "fp32_kernel": other["roofline"]["kernel"], "fp32_achieved": other["roofline"]["achieved"],
+                         "fp32_peak": PEAK["fp32"], "fp32_frac": other["roofline"]["frac"],
+                         "fp32_step_frac_of_mfma_roof": other["roofline"]["step_frac_of_mfma_roof"]})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -221,19 +299,23 @@ def main():
         cpu = {"value": round(v, 1), "unit": "samples/s", "cores": threads, "kind": "port",
                "sample": f"{ncpu} timed steps (+2 warm-up) of 4096+4096 rows on a {n_sub}-row image subset, "
                          f"reference-shaped torch-CPU loop (DataLoader collate, 3 backward passes, per-step scalars)",
-               "seconds": round(secs, 2), "bare_math_value": round(vb, 1), "host_cores_visible": cores}
+               "seconds": round(secs, 2), "bare_math_value": round(vb, 1), "host_cores_visible": cores,
+               "calibration": cpu_loop.CALIBRATION}
 
     if rank == 0:
         out = {"metric": METRIC, "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
-               "data": "synthetic",
+               "data": "synthetic", "repeats": repeats, "prime_steps": args.prime, "rccl_ranks": rccl_ranks,
                "config": {"workload": "cfg2 ImageNet-1k CLIP-ViT-B/16 features (d=512) + unpaired CUPL text, linear head "
                                       "C=1000, 4096 img + 4096 txt rows/step/GPU, scale 100, zero-shot init, AdamW "
                                       "lr 1e-3 wd 0.01, warm-up 50 + cosine 12800",
                           "n_img_rows": N_IMG, "n_txt_rows": N_TXT, "global_batch": 2 * BATCH * world,
                           "parallelism": f"dp{world}" + (" (REHEARSAL: ranks share GPUs, gloo all-reduce -- not a measurement)" if rehearsal else ""),
-                          "precision_mode": args.precision, "order_rng": args.order_rng, "steps_per_call": args.block},
+                          "dp_stepping": ("c-level rccl" if head["c_level_dp"] else "python per step") if dp_path else "single gpu",
+                          "precision_mode": args.precision, "order_rng": args.order_rng, "steps_per_call": args.block,
+                          "timing": f"median of {repeats} blocks of {args.steps} steps after {args.prime}+{args.warmup} untimed steps"},
+               "block_ms_per_step": head["block_ms_per_step"],
                "final_loss": {"img": round(final[0], 4), "txt": round(final[1], 4)},
                "host_enqueue_ms_per_step": round(head["host_enqueue_ms_per_step"], 4),
                "roofline": roofline, "cpu_baseline": cpu}

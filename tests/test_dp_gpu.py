@@ -134,3 +134,51 @@ def test_indexed_dp_path_two_ranks_vs_single(precision):
     tol = 1e-6 if precision == "fp32" else 3e-3
     for rank, w in res[2]:
         np.testing.assert_allclose(w, ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=0)
+
+
+def test_unequal_shards_rank_without_image_rows_applies_the_same_update():
+    """A rank whose image shard is empty (uneven shards / global batch < world size) must still step img_proj and
+    img_scale from the all-reduced gradient: the update is gated on the GLOBAL row counts.  Two ranks are emulated by
+    two engines in one process, the all-reduce by a sum of their flat gradient buffers."""
+    import umlh
+    rng = np.random.default_rng(21)
+    dv, dt, C, Bi, Bt = 48, 64, 10, 24, 40
+    xi = rng.standard_normal((Bi, dv)).astype(np.float32)
+    xt = rng.standard_normal((Bt, dt)).astype(np.float32)
+    yi, yt = rng.integers(0, C, Bi), rng.integers(0, C, Bt)
+    wp = (rng.standard_normal((dt, dv)) * 0.1).astype(np.float32)
+    wh = (rng.standard_normal((C, dt)) * 0.1).astype(np.float32)
+    dev = "cuda:0"
+    T = lambda a, t: torch.as_tensor(a).to(dev, t).contiguous()
+
+    def engine():
+        e = umlh.HeadEngine(dv, dt, C, has_proj=True, learnable_temp=True, optimizer="adamw", weight_decay=0.01,
+                            max_rows_img=64, max_rows_txt=64, device=dev)
+        e.w_head.copy_(torch.from_numpy(wh)); e.w_proj.copy_(torch.from_numpy(wp)); e.scales.fill_(3.0)
+        return e
+
+    ref = engine()
+    ref.train_step(umlh.RowBatch(T(xi, torch.float32), T(yi, torch.int64)), umlh.RowBatch(T(xt, torch.float32), T(yt, torch.int64)),
+                   lr=1e-2, step=1)
+    r0, r1 = engine(), engine()
+    half = Bt // 2
+    idx0, idx1 = torch.arange(0, half, device=dev), torch.arange(half, Bt, device=dev)
+    g0 = r0.grad_step(umlh.RowBatch(T(xi, torch.float32), T(yi, torch.int64), global_rows=Bi),
+                      umlh.RowBatch(T(xt, torch.float32), T(yt, torch.int64), idx0, global_rows=Bt))
+    g1 = r1.grad_step(umlh.RowBatch(T(xi, torch.float32), T(yi, torch.int64), rows=0, global_rows=Bi),
+                      umlh.RowBatch(T(xt, torch.float32), T(yt, torch.int64), idx1, global_rows=Bt))
+    tot = g0 + g1
+    g0.copy_(tot); g1.copy_(tot)
+    r0.apply_update(lr=1e-2, step=1); r1.apply_update(lr=1e-2, step=1)
+    torch.cuda.synchronize()
+    for name in ("w_head", "w_proj", "scales", "m_proj", "v_proj", "m_scales", "v_scales"):
+        a, b, c = (getattr(e, name).cpu().numpy() for e in (r0, r1, ref))
+        np.testing.assert_array_equal(a, b, err_msg=name)                       # replicas stay identical
+        assert np.abs(a - c).max() < 2e-3 * max(1.0, np.abs(c).max()), name      # == the single-GPU step (Adam sign flips at |g|~eps aside)
+    assert np.abs(r1.w_proj.cpu().numpy() - wp).max() > 1e-4                     # the rank without image rows did step img_proj
+
+    # a rank with no local row at all contributes zeros and still applies the update
+    r2 = engine()
+    g2 = r2.grad_step(umlh.RowBatch(T(xi, torch.float32), T(yi, torch.int64), rows=0, global_rows=Bi),
+                      umlh.RowBatch(T(xt, torch.float32), T(yt, torch.int64), rows=0, global_rows=Bt))
+    assert float(g2.abs().max()) == 0.0

@@ -157,3 +157,30 @@ def test_host_cpu_budget_and_thread_fit():
     assert 1 <= b <= (os.cpu_count() or 1)
     if "OMP_NUM_THREADS" not in os.environ:
         assert torch.get_num_threads() <= b
+
+
+def test_zero_shot_init_condition_mirrors_reference_setup():
+    """reference finetune.py:362-363: zero-shot head for crossmodal runs, or image-only runs whose common_dim equals the
+    text width; default unimodal runs (common_dim 0) and every text-only run keep the random nn.Linear init."""
+    from finetune import wants_zero_shot_init as w
+    assert w("zeroshot", "crossmodal", 0, 512)
+    assert w("zeroshot", "image", 512, 512)
+    assert not w("zeroshot", "image", 0, 512)           # CLIP features: d_img == d_txt must NOT trigger it
+    assert not w("zeroshot", "image", 768, 512)
+    assert not w("zeroshot", "text", 512, 512)
+    assert not w("zeroshot", "text", 0, 512)
+    assert not w("random", "crossmodal", 0, 512)
+
+
+def test_multibench_dropout_seeds_do_not_consume_the_global_cpu_generator():
+    """The loaders' shuffles draw from the global CPU generator (as the reference's DataLoaders do); dropout mask
+    seeds must come from a module-private generator so batch orders stay those of the reference."""
+    from multibench.models import Transformer
+    torch.manual_seed(5)
+    enc = Transformer(8, 10, nhead=5, num_layers=1)
+    state = torch.get_rng_state()
+    a, b = enc._dropout_seed(), enc._dropout_seed()
+    assert a != b and torch.equal(torch.get_rng_state(), state)
+    torch.manual_seed(5)
+    enc2 = Transformer(8, 10, nhead=5, num_layers=1)
+    assert enc2._dropout_seed() == a                     # still fixed by torch.manual_seed

@@ -165,6 +165,19 @@ struct umlh_handle_s {
     int dbg_fwd, dbg_dw;        // timing-only ablation / cycle-stamp switches (UMLH_DBG_FWD / UMLH_DBG_DW), read once at create
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
     bool profiling;
+    int device;                 // HIP device the handle was created on: every launching entry point runs there
+    int global_rows_img, global_rows_txt;   // global row counts of the last umlh_grad_step (gate the update on every rank alike)
+};
+
+// Every entry point that launches kernels for a handle makes the handle's device current for its duration
+// (a process may drive several GPUs; the caller's current device is restored on return).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int want) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != want && hipSetDevice(want) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
 static inline void mark(umlh_handle_t h, int i, hipStream_t st) {
@@ -215,7 +228,10 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
         h->ts = umlh_bf16_fwd_ts(h->wc, h->stw);
     }
     h->last_rows_img = h->last_rows_txt = 0;
+    h->global_rows_img = h->global_rows_txt = 0;
     h->profiling = false;
+    h->device = 0;
+    (void)hipGetDevice(&h->device);
     memset(&h->buf, 0, sizeof(h->buf));
     *out = h;
     return UMLH_OK;
@@ -223,6 +239,7 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
 
 int umlh_profile_enable(umlh_handle_t h, int enable) {
     if (!h) return fail(UMLH_E_INVALID, "umlh_profile_enable: null handle");
+    DeviceGuard dg_(h->device);
     if (enable && !h->profiling) {
         for (int i = 0; i <= UMLH_N_PHASES; ++i)
             if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(UMLH_E_HIP, "umlh_profile_enable: hipEventCreate failed");
@@ -237,6 +254,7 @@ int umlh_profile_enable(umlh_handle_t h, int enable) {
 int umlh_profile_read(umlh_handle_t h, float* ms_out) {
     if (!h || !ms_out) return fail(UMLH_E_INVALID, "umlh_profile_read: null argument");
     if (!h->profiling) return fail(UMLH_E_INVALID, "umlh_profile_read: profiling not enabled");
+    DeviceGuard dg_(h->device);
     if (hipEventSynchronize(h->ev[UMLH_N_PHASES]) != hipSuccess) return fail(UMLH_E_HIP, "umlh_profile_read: sync failed");
     for (int i = 0; i < UMLH_N_PHASES; ++i)
         if (hipEventElapsedTime(&ms_out[i], h->ev[i], h->ev[i + 1]) != hipSuccess)
@@ -323,6 +341,7 @@ int umlh_zero_shot_init(umlh_handle_t h, const float* text_feats, const int64_t*
                         void* stream) {
     if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_zero_shot_init: handle not bound");
     if (!text_feats || !text_labels || n_text < 0) return fail(UMLH_E_INVALID, "umlh_zero_shot_init: bad arguments");
+    DeviceGuard dg_(h->device);
     HIPCHK(umlh_launch_zero_shot(text_feats, text_labels, n_text, h->cfg.d_shared, h->cfg.num_classes,
                                  h->buf.w_head, (hipStream_t)stream), "zero_shot");
     return UMLH_OK;
@@ -344,6 +363,7 @@ static int launch_proj_forward(umlh_handle_t h, const umlh_batch_t* img, float* 
 int umlh_logits(umlh_handle_t h, const umlh_batch_t* b, int modality, float* out, void* stream) {
     if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_logits: handle not bound");
     if (!b || !out || (modality != 0 && modality != 1)) return fail(UMLH_E_INVALID, "umlh_logits: bad arguments");
+    DeviceGuard dg_(h->device);
     int rc = check_batch(h, b, modality == 0 ? h->L.rcap_img : h->L.rcap_txt, "umlh_logits");
     if (rc) return rc;
     if (b->rows == 0) return UMLH_OK;
@@ -373,6 +393,7 @@ int umlh_project(umlh_handle_t h, const umlh_batch_t* b, float* out, void* strea
     if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_project: handle not bound");
     if (!b || !out) return fail(UMLH_E_INVALID, "umlh_project: null argument");
     if (!h->cfg.has_proj) return fail(UMLH_E_INVALID, "umlh_project: head has no img_proj");
+    DeviceGuard dg_(h->device);
     int rc = check_batch(h, b, h->L.rcap_img, "umlh_project");
     if (rc) return rc;
     if (b->rows == 0) return UMLH_OK;
@@ -798,13 +819,16 @@ static FinalizeArgs make_finalize(umlh_handle_t h, const umlh_batch_t* img, cons
     f.scalars_out = scalars_out;
     f.scales = h->buf.scales; f.m_scales = h->buf.m_scales; f.v_scales = h->buf.v_scales;
     f.update_mask = 0;
-    if (update && h->cfg.learnable_temp) f.update_mask = (ri > 0 ? 1 : 0) | (rt > 0 ? 2 : 0);
+    // a parameter is stepped iff its modality has rows on ANY rank (torch skips parameters without a gradient):
+    // the data-parallel update must take the same decision on every rank, so it looks at the GLOBAL row counts
+    const int gi = img ? img->global_rows : h->global_rows_img, gt = txt ? txt->global_rows : h->global_rows_txt;
+    if (update && h->cfg.learnable_temp) f.update_mask = ((img ? ri : gi) > 0 ? 1 : 0) | ((txt ? rt : gt) > 0 ? 2 : 0);
     if (hy) f.opt = make_opt(h->cfg, *hy);
     return f;
 }
 
 static int check_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
-                      const char* who) {
+                      const char* who, bool allow_empty_local = false) {
     if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "%s: handle not bound", who);
     if (!hy) return fail(UMLH_E_INVALID, "%s: hyper is null", who);
     int rc = check_batch(h, img, h->cfg.max_rows_img, who);
@@ -812,7 +836,11 @@ static int check_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch
     rc = check_batch(h, txt, h->cfg.max_rows_txt, who);
     if (rc) return rc;
     // finetune.py:123 "At least one of the loaders should be provided"
-    if ((img ? img->rows : 0) + (txt ? txt->rows : 0) == 0) return fail(UMLH_E_INVALID, "%s: both modalities empty", who);
+    if ((img ? img->rows : 0) + (txt ? txt->rows : 0) == 0) {
+        // data-parallel split: a rank may hold no row of a (small or unevenly sharded) global batch
+        if (allow_empty_local && (img ? img->global_rows : 0) + (txt ? txt->global_rows : 0) > 0) return UMLH_OK;
+        return fail(UMLH_E_INVALID, "%s: both modalities empty", who);
+    }
     return UMLH_OK;
 }
 
@@ -855,6 +883,7 @@ int umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t
                     float* scalars_out, void* stream) {
     int rc = check_step(h, img, txt, hy, "umlh_train_step");
     if (rc) return rc;
+    DeviceGuard dg_(h->device);
     h->shadow_fresh = false;          // the caller may have rewritten w_head since the last call
     return train_step_impl(h, img, txt, hy, scalars_out, (hipStream_t)stream, false);
 }
@@ -866,6 +895,7 @@ int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_strea
     if (n_steps < 0 || !lr || (!img && !txt)) return fail(UMLH_E_INVALID, "umlh_train_steps: bad arguments");
     if ((img && (!img->offsets || !img->index)) || (txt && (!txt->offsets || !txt->index)))
         return fail(UMLH_E_INVALID, "umlh_train_steps: index/offsets required");
+    DeviceGuard dg_(h->device);
     for (int k = 0; k < n_steps; ++k) {
         umlh_batch_t bi, bt;
         memset(&bi, 0, sizeof(bi));
@@ -896,10 +926,20 @@ int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_strea
 
 int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
                    void* stream) {
-    int rc = check_step(h, img, txt, hy, "umlh_grad_step");
+    int rc = check_step(h, img, txt, hy, "umlh_grad_step", true);
     if (rc) return rc;
+    DeviceGuard dg_(h->device);
     hipStream_t st = (hipStream_t)stream;
     int sh = 0, sp = 0;
+    h->last_rows_img = img ? img->rows : 0;
+    h->last_rows_txt = txt ? txt->rows : 0;
+    h->global_rows_img = img ? img->global_rows : 0;
+    h->global_rows_txt = txt ? txt->global_rows : 0;
+    if (h->last_rows_img + h->last_rows_txt == 0) {       // no local row: this rank contributes zeros to the all-reduce
+        HIPCHK((int)hipMemsetAsync(ws(h, h->L.grads), 0, sizeof(float) * (h->L.n_head + h->L.n_proj + 2 + UMLH_N_SCALARS), st),
+               "zero gradient buffer");
+        return UMLH_OK;
+    }
     if (!(hy->flags & UMLH_F_WEIGHTS_UNCHANGED)) h->shadow_fresh = false;
     // the diagnostic slots of the flat buffer are zeroed (per-modality gradients of a data-parallel step
     // would need a second all-reduce; not produced)
@@ -924,8 +964,6 @@ int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t*
         else
             HIPCHK((int)hipMemsetAsync(grads + h->L.n_head, 0, sizeof(float) * h->L.n_proj, st), "zero proj grad");
     }
-    h->last_rows_img = img ? img->rows : 0;
-    h->last_rows_txt = txt ? txt->rows : 0;
     mark(h, 5, st);
     return UMLH_OK;
 }
@@ -947,6 +985,7 @@ int umlh_grad_buffer(umlh_handle_t h, float** device_ptr, uint64_t* n_floats) {
 int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_out, void* stream) {
     if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_apply_update: handle not bound");
     if (!hy) return fail(UMLH_E_INVALID, "umlh_apply_update: hyper is null");
+    DeviceGuard dg_(h->device);
     hipStream_t st = (hipStream_t)stream;
     OptArgs o = make_opt(h->cfg, *hy);
     float* grads = ws(h, h->L.grads);
@@ -962,7 +1001,7 @@ int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_ou
                                          h->buf.v_head, &o, st), "update head");
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
     }
-    if (h->cfg.has_proj && h->last_rows_img > 0)
+    if (h->cfg.has_proj && h->global_rows_img > 0)
         HIPCHK(umlh_launch_reduce_update(1, grads + h->L.n_head, 1, h->L.n_proj, h->L.n_proj, nullptr, h->buf.w_proj,
                                          h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
     return UMLH_OK;
@@ -971,6 +1010,7 @@ int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_ou
 int umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* b, float* scalars_out, void* stream) {
     if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_eval_batch: handle not bound");
     if (!b || !scalars_out) return fail(UMLH_E_INVALID, "umlh_eval_batch: null argument");
+    DeviceGuard dg_(h->device);
     int rc = check_batch(h, b, h->cfg.max_rows_img, "umlh_eval_batch");
     if (rc) return rc;
     if (b->rows == 0) return fail(UMLH_E_INVALID, "umlh_eval_batch: empty batch");
@@ -991,6 +1031,7 @@ int umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* b, float* scalars_out, 
 int umlh_eval_rows(umlh_handle_t h, const umlh_batch_t* b, float* row_stats, void* stream) {
     if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_eval_rows: handle not bound");
     if (!b || !row_stats) return fail(UMLH_E_INVALID, "umlh_eval_rows: null argument");
+    DeviceGuard dg_(h->device);
     int rc = check_batch(h, b, h->cfg.max_rows_img, "umlh_eval_rows");
     if (rc) return rc;
     if (b->rows == 0) return fail(UMLH_E_INVALID, "umlh_eval_rows: empty batch");

@@ -796,12 +796,14 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
 #define FWDB_CASE(CT, W, S)                                                                          \
     if (ctw == CT && wc == W && stw == S) {                                                          \
         size_t sm = fwd_smem_bytes_b(CT, W, S);                                                      \
-        static bool attr_done = false;                                                               \
-        if (!attr_done) {                                                                            \
+        static unsigned long long attr_done = 0;           /* bit d: done on device d (the attribute is per device) */ \
+        int dev_ = 0;                                                                                \
+        (void)hipGetDevice(&dev_);                                                                   \
+        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                  \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_bf16<CT, W, S>),\
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
             if (e != hipSuccess) return (int)e;                                                      \
-            attr_done = true;                                                                        \
+            attr_done |= 1ULL << (dev_ & 63);                                                        \
         }                                                                                            \
         hipLaunchKernelGGL((fwd_ce_bf16<CT, W, S>), dim3(grid), dim3(512), sm, stream, *a);          \
         return (int)hipGetLastError();                                                               \

@@ -794,12 +794,14 @@ static size_t fwd_smem_bytes(int ctw, int wc) {
 #define FWD_CASE_F(CT, W, F)                                                                        \
     if (ctw == CT && wc == W && fast == F) {                                                        \
         size_t sm = fwd_smem_bytes(CT, W);                                                          \
-        static bool attr_done = false;                     /* once per instantiation, not per launch */ \
-        if (!attr_done) {                                                                           \
+        static unsigned long long attr_done = 0;           /* bit d: done on device d (the attribute is per device) */ \
+        int dev_ = 0;                                                                               \
+        (void)hipGetDevice(&dev_);                                                                  \
+        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                 \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_f32<CT, W, F>),\
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);\
             if (e != hipSuccess) return (int)e;                                                     \
-            attr_done = true;                                                                       \
+            attr_done |= 1ULL << (dev_ & 63);                                                       \
         }                                                                                           \
         hipLaunchKernelGGL((fwd_ce_f32<CT, W, F>), dim3(grid), dim3(512), sm, stream, *a);          \
         return (int)hipGetLastError();                                                              \

@@ -292,16 +292,26 @@ def feature_tables(img_train, img_val, img_test, text_ds, device):
             "text": FeatureTable(text_ds.input_tensor, text_ds.label_tensor, device, text_ds.eot_indices)}
 
 
+def wants_zero_shot_init(classifier_init, modality, common_dim, text_indim):
+    """reference finetune.py:362-363: the text-derived head only for crossmodal runs, or an image-only run whose
+    ``common_dim`` equals the text width; every other unimodal run (default ``common_dim`` = 0, and all text-only
+    runs) keeps nn.Linear's random init."""
+    return classifier_init == "zeroshot" and (modality == "crossmodal" or
+                                              (modality == "image" and int(common_dim or 0) == int(text_indim)))
+
+
 def setup_feature_run(img_train, img_val, img_test, text_ds, hparams, *, num_classes, modality="crossmodal",
                       alpha=1.0, classifier_init="zeroshot", use_clip=False, clip_logit=4.60517, text_indim=None,
                       device="cuda:0", eval_test=True, precision="fp32", eval_freq=EVAL_FREQ, tables=None,
-                      generator=None, order_rng="torch-cpu", model=None):
+                      generator=None, order_rng="torch-cpu", model=None, common_dim=None):
     """``setup()`` (finetune.py:323-404) for pre-extracted features: builds the model,
     optimizer, scheduler and the four loaders with the reference's wiring, trains, tests.
 
     img_* are (features [N,d], labels [N]) pairs; text_ds a TextTensorDataset.  ``tables`` (from
     ``feature_tables``), ``generator`` (private seed source of the loaders) and a pre-built ``model``
-    are what the concurrent sweep passes in."""
+    are what the concurrent sweep passes in.  ``text_indim`` is ``args.text_indim`` in crossmodal mode and
+    ``args.common_dim`` otherwise (the second argument of ``UML(...)``, reference :343-346); ``common_dim``
+    overrides the latter."""
     d_img = img_train[0].shape[1]
     d_txt = text_ds.input_tensor.shape[1]
     if model is not None:
@@ -315,7 +325,9 @@ def setup_feature_run(img_train, img_val, img_test, text_ds, hparams, *, num_cla
     if tables is None:
         tables = feature_tables(img_train, img_val, img_test, text_ds, device)
     model.to(device)
-    if classifier_init == "zeroshot" and (modality == "crossmodal" or model.shared_dim == d_txt):
+    if common_dim is None:
+        common_dim = 0 if modality == "crossmodal" else (text_indim or 0)
+    if wants_zero_shot_init(classifier_init, modality, common_dim, d_txt):
         model.zero_shot_init(text_ds)
     optimizer = build_optimizer(model.parameters(), hparams["optim"], hparams["lr"], hparams["weight_decay"])
     scheduler = build_lr_scheduler(optimizer, hparams["lr_scheduler"], hparams["warmup_iter"], hparams["max_iter"],

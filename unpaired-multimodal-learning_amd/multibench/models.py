@@ -50,6 +50,18 @@ class Transformer(nn.Module):
                 table[:, 1::2] = torch.cos(pos * div)
                 self.register_buffer("pos_table", table)
 
+    def _dropout_seed(self):
+        """Seed of this forward's counter-based dropout masks, drawn from a generator PRIVATE to the module.  The
+        reference's dropout consumes the CUDA generator and leaves the global CPU generator to the DataLoader
+        samplers (MultiBench/train.py's two shuffled loaders): drawing mask seeds from the global CPU stream
+        would shift every batch order after the first epoch.  Seeded once from the process seed, so
+        ``torch.manual_seed`` still fixes the masks."""
+        g = getattr(self, "_drop_gen", None)
+        if g is None:
+            g = self._drop_gen = torch.Generator()
+            g.manual_seed((torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) % (2 ** 63))
+        return int(torch.randint(0, 2 ** 62, (1,), generator=g).item())
+
     def forward(self, x, lengths=None):
         """models.py:75-127 on the HIP encoder (multibench/encoder.py): conv1d -> positions -> causal
         transformer layers under the key-padding mask -> last valid token / all tokens."""
@@ -67,7 +79,7 @@ class Transformer(nn.Module):
         layers = self.transformer.layers
         l0 = layers[0]
         p = float(l0.dropout.p) if self.training else 0.0
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
+        seed = self._dropout_seed() if p > 0.0 else 0
         cfg = {"H": l0.self_attn.num_heads, "p": p, "eps": float(l0.norm1.eps), "seed": seed,
                "out_mode": ("last_len" if lengths is not None else "last") if self.out_last else "all"}
         params = [t for layer in layers for t in layer_params(layer)]

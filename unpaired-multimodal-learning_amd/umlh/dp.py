@@ -32,6 +32,14 @@ class DataParallelStepper:
         self._own_weights = False      # True once this stepper performed the last write of the weights
         self._flat = None
 
+    def attach_rccl(self) -> bool:
+        """Hand the engine an RCCL communicator of its own so that ``umlh_train_steps`` runs whole data-parallel
+        steps from C (grad -> ncclAllReduce -> update on the step's stream, no Python per step).  Needs an initialised
+        process group to exchange the unique id; returns False when the library was built without RCCL."""
+        if self.world <= 1 or not hasattr(self.engine, "init_rccl"):
+            return False
+        return bool(self.engine.init_rccl(self.group))
+
     def invalidate(self) -> None:
         """Call after writing the parameters from outside (load_state_dict, re-init)."""
         self._own_weights = False

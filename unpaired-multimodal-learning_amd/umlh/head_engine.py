@@ -63,7 +63,8 @@ class HeadEngine:
             raise UmlhError(f"unsupported head config: d_img={d_img} d_shared={d_shared} C={num_classes} "
                             f"has_proj={has_proj} precision={precision}")
         self.handle = C.c_void_p()
-        check(self.lib.umlh_create(C.byref(self.cfg), C.byref(self.handle)), "umlh_create")
+        with torch.cuda.device(self.device):           # the handle remembers its device; its entry points switch to it
+            check(self.lib.umlh_create(C.byref(self.cfg), C.byref(self.handle)), "umlh_create")
         f32 = dict(dtype=torch.float32, device=self.device)
         self.workspace = torch.empty(nbytes // 4, **f32)
         self.has_proj, self.learnable_temp, self.optimizer = bool(has_proj), bool(learnable_temp), optimizer
@@ -120,7 +121,8 @@ class HeadEngine:
             return None
         rows = b.n_rows()
         if rows == 0:
-            return None
+            # data-parallel split: an empty local shard still tells the update that the modality has rows elsewhere
+            return Batch(None, None, None, 0, int(b.global_rows), None) if b.global_rows else None
         f, y = b.feats, b.labels
         if f.dtype != torch.float32 or not f.is_contiguous() or f.dim() != 2 or f.shape[1] != dim:
             raise UmlhError(f"features must be contiguous fp32 [N,{dim}], got {f.dtype} {tuple(f.shape)}")
