@@ -208,7 +208,7 @@ def test_bf16_two_layer_head_training_tracks_fp32():
 
 def test_bf16_training_accuracy_parity_with_fp32():
     """Same seed, same batches: 300 AdamW steps in bf16 mode vs fp32 mode; final top-1 on
-    20k held-out rows within +-0.25 pp (north_star target +-0.1 pp; printed)."""
+    20k held-out rows within +-0.1 pp (north_star)."""
     import umlh
     rng = np.random.default_rng(11)
     d, C, n = 128, 100, 20000
@@ -239,7 +239,7 @@ def test_bf16_training_accuracy_parity_with_fp32():
         accs[prec] = sc[umlh.S_CORRECT] / 20000
     print(f"top-1 fp32 {accs['fp32']:.4f}  bf16 {accs['bf16']:.4f}  diff {100 * (accs['bf16'] - accs['fp32']):+.3f} pp")
     assert accs["fp32"] > 0.5
-    assert abs(accs["bf16"] - accs["fp32"]) <= 0.0025
+    assert abs(accs["bf16"] - accs["fp32"]) <= 0.001
 
 
 def test_bf16_two_layer_head_split_step_equals_fused_step():

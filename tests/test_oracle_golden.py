@@ -183,3 +183,42 @@ def test_full_train_run_matches_reference(tag):
         np.testing.assert_allclose(st.w_proj, g["w_proj_best"], atol=5e-6, rtol=1e-4)
     tl, ta = O.validate(st, g["x_test"], g["y_test"], B)
     assert abs(ta - float(g["test_acc"])) < 1e-6 and abs(tl - float(g["test_loss"])) < 1e-4
+
+
+def test_cfg1_shaped_full_train_run_matches_reference():
+    """The cfg1-shaped (d=512, C=100, 1600 img + 3000 txt rows, batch 32, clip_linear point, eval every 100) run of the
+    reference's own finetune.train() (tests/golden/train_cfg1.npz, generated by oracle/make_golden_cfg1.py; inputs are
+    regenerated from the numpy seed in oracle/fixtures_cfg1.py): the oracle replays 1500 iterations under the same
+    seeds -- batch order, per-step losses 1e-4, validation trace, best iteration, final top-1."""
+    import math
+    from oracle import fixtures_cfg1 as FX
+    g = load_golden("train_cfg1")
+    inp = FX.cfg1_inputs()
+    B = FX.BATCH
+    st = O.HeadState(O.zero_shot_weights(inp["x_txt"], inp["y_txt"], FX.C), None, math.exp(FX.SCALE_LOG), math.exp(FX.SCALE_LOG), False)
+    opt = O.OptState("adamw", FX.WD)
+    sched = O.LRSchedule(FX.LR, "cosine", 50, 12800, "linear", 1e-5)
+    torch.manual_seed(FX.SEED)
+    w = torch.nn.Linear(FX.D, FX.C, bias=False)                 # the head's init consumed the global RNG before train()
+    np.testing.assert_array_equal(w.weight.detach().numpy(), g["w_head_init"])
+    rec = {}
+    out = O.train_loop(st, opt, sched, (inp["x_img"], inp["y_img"]), (inp["x_txt"], inp["y_txt"]),
+                       (inp["x_val"], inp["y_val"]), (inp["x_test"], inp["y_test"]), B, FX.MAX_ITERS, FX.ALPHA,
+                       FX.EVAL_FREQ, FX.PATIENCE, record=rec)
+    n = int(g["n_steps"])
+    assert len(rec["loss_img"]) == n
+    ii, ti = np.concatenate(rec["idx_img"]), np.concatenate(rec["idx_txt"])
+    assert [ii.size, ti.size] == g["n_idx"].tolist()
+    np.testing.assert_array_equal(ii[:10 * B], g["idx_img_head"])
+    np.testing.assert_array_equal(ti[:10 * B], g["idx_txt_head"])
+    assert int((ii * (np.arange(ii.size) % 977 + 1)).sum()) == int(g["idx_img_checksum"][0])
+    assert int((ti * (np.arange(ti.size) % 977 + 1)).sum()) == int(g["idx_txt_checksum"][0])
+    ce = g["train_ce"]
+    np.testing.assert_allclose(rec["loss_img"], ce[0::2], atol=1e-4)
+    np.testing.assert_allclose(rec["loss_txt"], ce[1::2], atol=1e-4)
+    np.testing.assert_allclose(rec["val_acc"], g["val_acc"][:len(rec["val_acc"])], atol=1e-6)
+    np.testing.assert_allclose(rec["val_loss"], g["val_loss"][:len(rec["val_loss"])], atol=1e-4)
+    assert out["iter"] == int(g["best_iter"]) and abs(out["val_acc"] - float(g["best_val_acc"])) < 1e-6
+    np.testing.assert_allclose(st.w_head, g["w_head_best"], atol=2e-5, rtol=1e-3)
+    tl, ta = O.validate(st, inp["x_test"], inp["y_test"], B)
+    assert abs(ta - float(g["test_acc"])) <= 1e-3 and abs(tl - float(g["test_loss"])) < 1e-4
