@@ -181,6 +181,33 @@ int  umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_stre
                       const double* lr, int64_t first_step, float alpha, float img_alpha,
                       float* scalars_out, void* stream);
 
+/* Batch <= 64 linear heads (the reference's own operating point: batch 8 / 32 / 64, 12 800 iterations,
+ * engine/optimizer/default.py:3-45): umlh_train_steps runs all n_steps inside ONE persistent launch when the head is
+ * fp32, has no img_proj, its width has a supported chunking (d in {16,32,48,64,80,96,128,256,384,512,640,768,1024}),
+ * diagnostics are off and every step has at most 4 sample tiles (ceil(rows_img/16) + ceil(rows_txt/16) <= 4).  The
+ * class axis is cut into 16-class slices, one workgroup per slice owns its part of W / m / v for the whole call; the
+ * slices of a head exchange their softmax statistics once per step (in-launch, bounded waits).  UMLH_MICRO=0 in the
+ * environment disables the path.  A wait that gives up (another process starving the device of CUs) is reported
+ * through umlh_micro_status (0 = ok); the head's state is then undefined.
+ *
+ * umlh_train_steps_grouped: the sweep of finetune.py:406-448 (HYPER_DICT grid x alpha x seeds: many independent heads over
+ * the SAME feature tables) as grouped launches -- G heads [G, C, d] advance n_steps each inside the same persistent
+ * launch(es), every head with its own index streams, lr table, optimizer state and scalar rows.  Results are bit-identical
+ * to G separate umlh_train_steps calls.  Heads outside the micro envelope fall back to per-head stepping. */
+typedef struct {
+    umlh_handle_t handle;
+    const umlh_stream_t* img;    /* NULL = modality absent */
+    const umlh_stream_t* txt;
+    const double* lr;            /* HOST double[n_steps] */
+    int64_t first_step;
+    float   alpha, img_alpha;
+    float*  scalars_out;         /* device float[n_steps * UMLH_N_SCALARS] or NULL */
+} umlh_group_item_t;
+int  umlh_train_steps_grouped(const umlh_group_item_t* items, int32_t n_items, int32_t n_steps, void* stream);
+int  umlh_micro_status(umlh_handle_t h, int32_t* status_out);
+/* number of persistent micro-step launches this handle has taken part in (which path ran: tests, logging) */
+int  umlh_micro_launches(umlh_handle_t h, int64_t* out);
+
 /* Data-parallel split of the step: gradients only, laid out as ONE flat fp32
  * buffer [g_head | g_proj | g_scales(2) | scalars(UMLH_N_SCALARS)] inside the
  * workspace, already divided by batch->global_rows so a SUM all-reduce over ranks

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--workers", type=int, nargs="+", default=[1, 6, 12])
     ap.add_argument("--replicas", type=int, default=3, help="copies of the 6-point grid (stand-ins for alpha / seed axes)")
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--grouped", action="store_true", help="also time the sweep as one grouped job (sweep_mode='grouped': every "
+                                                          "grid point a head of the same persistent launches)")
     a = ap.parse_args()
     import finetune as ft
     from engine.datasets.utils import TextTensorDataset
@@ -47,11 +49,12 @@ def main():
     grid["dropout"] = [None] + [0.1 * (k + 1) for k in range(a.replicas - 1)]   # unused by the head: replicates the grid, distinct result dirs
     n_points = len(ft._grid(grid))
     out = []
-    for w in [1] + a.workers:                              # the first pass is an untimed warm-up (module load, allocator)
+    for w in [1] + a.workers + (["grouped"] if a.grouped else []):   # the first pass is an untimed warm-up (module load, allocator)
         with tempfile.TemporaryDirectory() as tmp:
             args = types.SimpleNamespace(savepath=tmp, device="cuda:0", modality="crossmodal", alpha=1.0,
                                          classifier_init="zeroshot", use_clip=True, logit=4.60517, nclasses=C, seed=1,
-                                         precision=a.precision, sweep_workers=w, eval_test=False, order_rng="torch-cpu")
+                                         precision=a.precision, sweep_workers=w if w != "grouped" else 1,
+                                         sweep_mode="grouped" if w == "grouped" else "", eval_test=False, order_rng="torch-cpu")
             devnull = open(os.devnull, "w")
             so = sys.stdout
             sys.stdout = devnull
@@ -68,10 +71,10 @@ def main():
                 main._warm = True
                 continue
             out.append((w, dt, steps / dt, bv))
-            print(f"workers={w:3d}  points={n_points}  {dt:7.2f} s  {steps / dt:10.0f} steps/s  {64 * steps / dt:12.0f} samples/s  best_val={bv:.4f}", flush=True)
+            print(f"workers={w!s:>7}  points={n_points}  {dt:7.2f} s  {steps / dt:10.0f} steps/s  {64 * steps / dt:12.0f} samples/s  best_val={bv:.4f}", flush=True)
     base = out[0][2]
     for w, dt, r, _ in out[1:]:
-        print(f"farm x{w}: {r / base:.2f}x the sequential sweep")
+        print(f"{'grouped launch' if w == 'grouped' else 'farm x%d' % w}: {r / base:.2f}x the sequential sweep")
 
 
 if __name__ == "__main__":

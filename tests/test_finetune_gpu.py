@@ -169,6 +169,43 @@ def test_sweep_farm_equals_isolated_runs(tmp_path):
     assert res2["val_acc"] == res["val_acc"]
 
 
+def test_grouped_sweep_equals_isolated_runs(tmp_path):
+    """The sweep as ONE grouped job (sweep_mode="grouped": every grid point a head of the same persistent launches,
+    umlh_train_steps_grouped) gives exactly what each point gives when run alone with the same private generator:
+    early-stop iteration, accuracies and best weights, bit for bit (finetune.py:406-448)."""
+    import types
+    import finetune as ft
+    from engine.datasets.utils import TextTensorDataset
+    from engine.models.head import UMLClip
+    tr, va, te, (xt, yt), C = _toy_dataset()
+    text_ds = TextTensorDataset(xt, yt, torch.zeros(len(yt), dtype=torch.long))
+    grid = {"optim": "adamw", "lr": [1e-3, 1e-4], "weight_decay": [0.0, 0.01, 0.001], "lr_scheduler": "cosine",
+            "batch_size": 16, "max_iter": [240, 130], "warmup_iter": 50, "warmup_type": "linear", "warmup_min_lr": 1e-5,
+            "patience": 2, "dropout": None, "learnable_temp": False}
+    datasets = {"img_tr": tr, "img_val": va, "img_te": te, "text_ds": text_ds}
+    args = types.SimpleNamespace(savepath=str(tmp_path), device=DEV, modality="crossmodal", alpha=1.0,
+                                 classifier_init="zeroshot", use_clip=True, logit=4.60517, nclasses=C, seed=3,
+                                 precision="fp32", sweep_mode="grouped", eval_test=True)
+    res, best_val, best_test = ft.sweep(datasets, grid, args)
+    points = ft._grid(grid)
+    assert len(res["val_acc"]) == len(points) == 12 and best_val == max(res["val_acc"])
+    iters = set()
+    for idx, hp in enumerate(points):
+        gen = torch.Generator()
+        gen.manual_seed(ft.farm_seed(3, idx))
+        torch.manual_seed(ft.farm_seed(3, idx))
+        model = UMLClip(tr[0].shape[1], C, logit_scale_init=4.60517, bias=False, learnable_temp=False)
+        solo = ft.setup_feature_run(tr, va, te, text_ds, hp, num_classes=C, use_clip=True, device=DEV, generator=gen,
+                                    model=model)
+        saved = torch.load(tmp_path / ft.hparam_str(hp["optim"], hp["lr"], hp["weight_decay"], 16, hp["max_iter"], None, False)
+                           / "test_result.pth", weights_only=True)
+        assert saved["iter"] == solo["iter"]
+        assert saved["val_acc"] == solo["val_acc"] == res["val_acc"][idx]
+        assert saved["test_acc"] == solo["test_acc"] == res["test_acc"][idx]
+        assert torch.equal(saved["model"]["head.weight"], solo["model"]["head.weight"])
+        iters.add(saved["iter"])
+
+
 @pytest.mark.parametrize("tag", ["lin_zs", "mlp_lt"])
 def test_logger_receives_reference_diagnostics(tag):
     """With a logger, train() logs per step what the reference logs (finetune.py:236-240): losses, accuracies, lr, the

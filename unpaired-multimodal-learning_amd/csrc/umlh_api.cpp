@@ -10,8 +10,12 @@
 #include <new>
 
 #include "umlh_common.h"
+#include "umlh_micro.h"
+#include <mutex>
 
 extern "C" {
+int umlh_micro_chunking(int d, int* nch, int* cw);
+int umlh_micro_launch(int nch, int cw, const UmlhMicroHead* heads, int n_heads, int n_steps, int grid, hipStream_t st);
 int umlh_f32_fwd_config(int C, int* ctw, int* wc);
 int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t stream);
 int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream);
@@ -65,6 +69,8 @@ static inline long long round_up(long long x, long long m) { return (x + m - 1) 
 
 struct Layout {                 // workspace partition, in floats from the base
     long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, iota, zeros, dbg, wpt16, wht16, total;
+    long long mc_flags, mc_xchg, mc_ext, mc_tab, mc_desc;   // micro-step region (umlh_kernels_micro.hip); mc_flags = 0: unsupported shape
+    int mc_nwg, mc_nch, mc_cw;
     long long n_iota;
     int rcap_img, rcap_txt, ldz;     // padded row capacities
     int scap_head, scap_proj;        // split-K slab capacities
@@ -101,6 +107,11 @@ static SplitPlan plan_splits(int r0, int r1, int want, int quantum, int min_chun
     sp.n_img = (int)((r0 + chunk - 1) / chunk);
     sp.n_txt = (int)((r1 + chunk - 1) / chunk);
     return sp;
+}
+
+// per-launch tables of one head: int offs_img[MAXS + 1], int offs_txt[MAXS + 1], OptArgs opt[MAXS]
+static long long micro_table_floats() {
+    return 2LL * (UMLH_MICRO_MAX_STEPS + 1) + 2 + (long long)UMLH_MICRO_MAX_STEPS * (sizeof(OptArgs) / sizeof(float));
 }
 
 static bool make_layout(const umlh_config_t& c, Layout& L) {
@@ -143,6 +154,17 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     const bool bfp = c.precision == UMLH_PREC_BF16 && c.has_proj;
     L.wpt16 = take(bfp ? (L.n_proj + 1) / 2 : 0);         // bf16 W_proj^T [d_img][d_shared]
     L.wht16 = take(bfp ? 1024LL * round_up(c.d_shared, 128) / 2 : 0);   // bf16 W_head^T by class chunks [16][d_shared^128][64]
+    // micro-step path: fp32 linear head whose width has a supported chunking
+    L.mc_flags = L.mc_xchg = L.mc_ext = L.mc_tab = L.mc_desc = 0;
+    L.mc_nwg = (c.num_classes + UMLH_MICRO_CS - 1) / UMLH_MICRO_CS;
+    L.mc_nch = L.mc_cw = 0;
+    if (c.precision == UMLH_PREC_FP32 && !c.has_proj && umlh_micro_chunking(c.d_shared, &L.mc_nch, &L.mc_cw)) {
+        L.mc_flags = take(64 + 64);                                              // [nwg <= 64] epoch flags, then the status word
+        L.mc_xchg = take(2LL * L.mc_nwg * 5 * UMLH_MICRO_MAX_ROWS * 2);       // 8-byte granules
+        L.mc_ext = 0;
+        L.mc_tab = take(micro_table_floats());
+        L.mc_desc = take((long long)UMLH_MICRO_MAX_HEADS * sizeof(UmlhMicroHead) / sizeof(float) + 16);
+    }
     L.total = off;
     return true;
 }
@@ -165,6 +187,14 @@ struct umlh_handle_s {
     int dbg_fwd, dbg_dw;        // timing-only ablation / cycle-stamp switches (UMLH_DBG_FWD / UMLH_DBG_DW), read once at create
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
     bool profiling;
+    // micro-step path
+    unsigned micro_epoch;       // last epoch published by this handle's workgroups (flags are zeroed at bind)
+    unsigned char* stage;       // pinned host staging [2][stage_bytes] for the per-launch tables / descriptors (lazy)
+    size_t stage_bytes;
+    hipEvent_t stage_ev[2];     // copy-out of staging buffer i has completed
+    int stage_next;
+    int micro_off;              // UMLH_MICRO=0: never take the micro path
+    long long micro_launches;   // persistent launches this handle took part in (tests assert the path that ran)
     int device;                 // HIP device the handle was created on: every launching entry point runs there
     int global_rows_img, global_rows_txt;   // global row counts of the last umlh_grad_step (gate the update on every rank alike)
 };
@@ -230,6 +260,10 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->last_rows_img = h->last_rows_txt = 0;
     h->global_rows_img = h->global_rows_txt = 0;
     h->profiling = false;
+    h->micro_epoch = 0;
+    h->micro_launches = 0;
+    h->stage = nullptr; h->stage_bytes = 0; h->stage_next = 0;
+    { const char* e = getenv("UMLH_MICRO"); h->micro_off = (e && atoi(e) == 0) ? 1 : 0; }
     h->device = 0;
     (void)hipGetDevice(&h->device);
     memset(&h->buf, 0, sizeof(h->buf));
@@ -264,9 +298,17 @@ int umlh_profile_read(umlh_handle_t h, float* ms_out) {
 
 int umlh_destroy(umlh_handle_t h) {
     if (h && h->profiling) umlh_profile_enable(h, 0);
+    if (h && h->stage) {
+        DeviceGuard dg_(h->device);
+        (void)hipEventSynchronize(h->stage_ev[0]); (void)hipEventSynchronize(h->stage_ev[1]);
+        (void)hipEventDestroy(h->stage_ev[0]); (void)hipEventDestroy(h->stage_ev[1]);
+        (void)hipHostFree(h->stage);
+    }
     delete h;
     return UMLH_OK;
 }
+
+static inline float* ws(umlh_handle_t h, long long off) { return static_cast<float*>(h->buf.workspace) + off; }
 
 int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
     if (!h || !b) return fail(UMLH_E_INVALID, "umlh_bind: null argument");
@@ -285,6 +327,12 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
     h->bound = true;
     h->iota_ready = false;
     h->shadow_fresh = false;
+    if (h->L.mc_flags) {          // epoch flags, status word and exchange records start from zero (bind time only)
+        DeviceGuard dg_(h->device);
+        const size_t n = (size_t)(h->L.mc_tab - h->L.mc_flags) * sizeof(float);
+        if (hipMemset(ws(h, h->L.mc_flags), 0, n) != hipSuccess) return fail(UMLH_E_HIP, "umlh_bind: clearing the micro-step region failed");
+        h->micro_epoch = 0;
+    }
     return UMLH_OK;
 }
 
@@ -299,8 +347,6 @@ static inline int fwd_blocks_img(const umlh_handle_s* h, int rows) {
     }
     return nb;
 }
-
-static inline float* ws(umlh_handle_t h, long long off) { return static_cast<float*>(h->buf.workspace) + off; }
 
 static int check_batch(umlh_handle_t h, const umlh_batch_t* b, int cap, const char* who) {
     if (!b) return UMLH_OK;
@@ -879,6 +925,215 @@ static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_
     return UMLH_OK;
 }
 
+
+// --------------------------------------------------------------------------------------------------------------- //
+// micro-step path (umlh_kernels_micro.hip): whole evaluation intervals of one or MANY heads in one persistent launch
+// --------------------------------------------------------------------------------------------------------------- //
+struct MicroItem {
+    umlh_handle_t h;
+    const umlh_stream_t* img; const umlh_stream_t* txt;
+    const double* lr; int64_t first_step; float alpha, img_alpha; float* scalars_out;
+};
+
+static int device_cus(int dev) {
+    static int cus[64];
+    static std::once_flag once[64];
+    const int d = dev & 63;
+    std::call_once(once[d], [&] {
+        hipDeviceProp_t p;
+        cus[d] = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 0;
+    });
+    return cus[d];
+}
+
+// Shape / row-count test of the micro path for `n_steps` steps of one head (no side effects).
+static bool micro_eligible(umlh_handle_t h, const umlh_stream_t* img, const umlh_stream_t* txt, int n_steps) {
+    if (!h->L.mc_flags || h->micro_off || h->diagnostics || h->profiling || n_steps < 1) return false;
+    if (h->L.mc_nwg > device_cus(h->device) || h->L.mc_nwg > 64) return false;
+    for (int k = 0; k < n_steps; ++k) {
+        const int ri = img ? img->offsets[k + 1] - img->offsets[k] : 0, rt = txt ? txt->offsets[k + 1] - txt->offsets[k] : 0;
+        if (ri < 0 || rt < 0 || ri + rt == 0) return false;
+        if (ri > h->cfg.max_rows_img || rt > h->cfg.max_rows_txt) return false;
+        if ((ri + 15) / 16 + (rt + 15) / 16 > UMLH_MICRO_MAX_ROWS / 16) return false;
+    }
+    return true;
+}
+
+static int micro_stage(umlh_handle_t h, unsigned char** out) {
+    const size_t need = (size_t)micro_table_floats() * sizeof(float) + (size_t)UMLH_MICRO_MAX_HEADS * sizeof(UmlhMicroHead) + 64;
+    if (!h->stage) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->stage), 2 * need, hipHostMallocDefault) != hipSuccess)
+            return fail(UMLH_E_HIP, "micro step: pinned staging allocation failed");
+        h->stage_bytes = need;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming) != hipSuccess) return fail(UMLH_E_HIP, "micro step: event");
+        (void)hipEventRecord(h->stage_ev[0], nullptr); (void)hipEventRecord(h->stage_ev[1], nullptr);
+    }
+    const int i = h->stage_next;
+    h->stage_next ^= 1;
+    if (hipEventSynchronize(h->stage_ev[i]) != hipSuccess) return fail(UMLH_E_HIP, "micro step: staging event");   // copy-out of its last use finished
+    *out = h->stage + (size_t)i * h->stage_bytes;
+    return i;
+}
+
+// Micro launches of one process on one device run one after the other, also when they are enqueued on different
+// streams: two persistent grids that are each resident alone could otherwise strand each other's workgroups.
+static std::mutex g_micro_mu;
+static hipEvent_t g_micro_ev[64];
+static bool g_micro_ev_ok[64];
+
+// One launch: `n` heads x `n_steps` steps starting at step offset `k0` of every item's streams.
+static int micro_launch_group(const MicroItem* it, int n, int k0, int n_steps, hipStream_t st) {
+    umlh_handle_t h0 = it[0].h;
+    unsigned char* stage0 = nullptr;
+    const int sidx0 = micro_stage(h0, &stage0);
+    if (sidx0 < 0) return sidx0;
+    const size_t tab_bytes = (size_t)micro_table_floats() * sizeof(float);
+    UmlhMicroHead* descs = reinterpret_cast<UmlhMicroHead*>(stage0 + tab_bytes);
+    int grid = 0;
+    for (int i = 0; i < n; ++i) {
+        umlh_handle_t h = it[i].h;
+        unsigned char* stg = stage0;
+        int sidx = sidx0;
+        if (i > 0) { sidx = micro_stage(h, &stg); if (sidx < 0) return sidx; }
+        int* offs_i = reinterpret_cast<int*>(stg);
+        int* offs_t = offs_i + UMLH_MICRO_MAX_STEPS + 1;
+        OptArgs* opt = reinterpret_cast<OptArgs*>(offs_t + UMLH_MICRO_MAX_STEPS + 1 + 2);
+        for (int k = 0; k <= n_steps; ++k) {
+            offs_i[k] = it[i].img ? it[i].img->offsets[k0 + k] : 0;
+            offs_t[k] = it[i].txt ? it[i].txt->offsets[k0 + k] : 0;
+        }
+        for (int k = 0; k < n_steps; ++k) {
+            umlh_hyper_t hy;
+            memset(&hy, 0, sizeof(hy));
+            hy.lr = it[i].lr[k0 + k]; hy.step = it[i].first_step + k0 + k;
+            opt[k] = make_opt(h->cfg, hy);
+        }
+        float* dtab = ws(h, h->L.mc_tab);
+        HIPCHK((int)hipMemcpyAsync(dtab, stg, tab_bytes, hipMemcpyHostToDevice, st), "micro step: table upload");
+        if (i > 0) HIPCHK((int)hipEventRecord(h->stage_ev[sidx], st), "micro step: staging event");
+        UmlhMicroHead& d = descs[i];
+        memset(&d, 0, sizeof(d));
+        const umlh_stream_t* s2[2] = {it[i].img, it[i].txt};
+        int* doffs[2] = {reinterpret_cast<int*>(dtab), reinterpret_cast<int*>(dtab) + UMLH_MICRO_MAX_STEPS + 1};
+        for (int m = 0; m < 2; ++m) {
+            if (!s2[m]) continue;
+            d.feats[m] = s2[m]->feats; d.labels[m] = s2[m]->labels; d.index[m] = s2[m]->index; d.offs[m] = doffs[m];
+        }
+        d.w = h->buf.w_head; d.m = h->buf.m_head; d.v = h->buf.v_head;
+        d.scales = h->buf.scales; d.m_scales = h->buf.m_scales; d.v_scales = h->buf.v_scales;
+        d.opt = reinterpret_cast<const OptArgs*>(reinterpret_cast<int*>(dtab) + 2 * (UMLH_MICRO_MAX_STEPS + 1) + 2);
+        d.scalars_out = it[i].scalars_out ? it[i].scalars_out + (size_t)k0 * UMLH_N_SCALARS : nullptr;
+        d.xchg = reinterpret_cast<unsigned long long*>(ws(h, h->L.mc_xchg));
+        d.status = reinterpret_cast<unsigned*>(ws(h, h->L.mc_flags)) + 64;
+        static const bool dbg_micro = [] { const char* e = getenv("UMLH_DBG_MICRO"); return e && atoi(e) == 1; }();
+        d.stamps = (dbg_micro && (long long)h->L.max_blocks * 128 * sizeof(float) >= (size_t)h->L.mc_nwg * 96)
+                       ? reinterpret_cast<unsigned long long*>(ws(h, h->L.dbg)) : nullptr;
+        d.epoch0 = h->micro_epoch;
+        h->micro_epoch += (unsigned)n_steps;
+        h->micro_launches += 1;
+        d.C = h->cfg.num_classes; d.d = h->cfg.d_shared; d.nwg = h->L.mc_nwg; d.wg0 = grid;
+        d.learnable = h->cfg.learnable_temp; d.opt_kind = h->cfg.optimizer;
+        d.w_img = it[i].img_alpha; d.w_txt = it[i].alpha;
+        grid += d.nwg;
+        h->shadow_fresh = false;
+    }
+    UmlhMicroHead* ddesc = reinterpret_cast<UmlhMicroHead*>(ws(h0, h0->L.mc_desc));
+    HIPCHK((int)hipMemcpyAsync(ddesc, descs, sizeof(UmlhMicroHead) * (size_t)n, hipMemcpyHostToDevice, st), "micro step: descriptor upload");
+    HIPCHK((int)hipEventRecord(h0->stage_ev[sidx0], st), "micro step: staging event");
+    {
+        std::lock_guard<std::mutex> lk(g_micro_mu);
+        const int dv = h0->device & 63;
+        if (!g_micro_ev_ok[dv]) {
+            HIPCHK((int)hipEventCreateWithFlags(&g_micro_ev[dv], hipEventDisableTiming), "micro step: chain event");
+            g_micro_ev_ok[dv] = true;
+        } else {
+            HIPCHK((int)hipStreamWaitEvent(st, g_micro_ev[dv], 0), "micro step: chain wait");
+        }
+        HIPCHK(umlh_micro_launch(h0->L.mc_nch, h0->L.mc_cw, ddesc, n, n_steps, grid, st), "micro_steps_kernel");
+        HIPCHK((int)hipEventRecord(g_micro_ev[dv], st), "micro step: chain record");
+    }
+    return UMLH_OK;
+}
+
+// All items: same number of steps; heads of one launch share the chunking (feature width) and fit the chip together.
+static int micro_run(const MicroItem* it, int n_items, int n_steps, hipStream_t st) {
+    const int cus = device_cus(it[0].h->device);
+    for (int k0 = 0; k0 < n_steps; k0 += UMLH_MICRO_MAX_STEPS) {
+        const int ns = n_steps - k0 < UMLH_MICRO_MAX_STEPS ? n_steps - k0 : UMLH_MICRO_MAX_STEPS;
+        int a = 0;
+        while (a < n_items) {
+            int b = a, wgs = 0;
+            while (b < n_items && b - a < UMLH_MICRO_MAX_HEADS && wgs + it[b].h->L.mc_nwg <= cus &&
+                   it[b].h->cfg.d_shared == it[a].h->cfg.d_shared) {
+                wgs += it[b].h->L.mc_nwg;
+                ++b;
+            }
+            if (b == a) return fail(UMLH_E_INVALID, "micro step: head %d does not fit the device", a);
+            int rc = micro_launch_group(it + a, b - a, k0, ns, st);
+            if (rc) return rc;
+            a = b;
+        }
+    }
+    return UMLH_OK;
+}
+
+int umlh_micro_status(umlh_handle_t h, int32_t* status_out) {
+    if (!h || !h->bound || !status_out) return fail(UMLH_E_INVALID, "umlh_micro_status: bad arguments");
+    *status_out = 0;
+    if (!h->L.mc_flags) return UMLH_OK;
+    DeviceGuard dg_(h->device);
+    unsigned v = 0;
+    HIPCHK((int)hipMemcpy(&v, reinterpret_cast<unsigned*>(ws(h, h->L.mc_flags)) + 64, sizeof(v), hipMemcpyDeviceToHost), "umlh_micro_status");
+    *status_out = (int32_t)v;
+    return UMLH_OK;
+}
+
+int umlh_micro_launches(umlh_handle_t h, int64_t* out) {
+    if (!h || !out) return fail(UMLH_E_INVALID, "umlh_micro_launches: bad arguments");
+    *out = h->micro_launches;
+    return UMLH_OK;
+}
+
+static int check_streams(umlh_handle_t h, const umlh_stream_t* img, const umlh_stream_t* txt, int32_t n_steps, const double* lr,
+                         const char* who) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "%s: handle not bound", who);
+    if (n_steps < 0 || !lr || (!img && !txt)) return fail(UMLH_E_INVALID, "%s: bad arguments", who);
+    if ((img && (!img->offsets || !img->index)) || (txt && (!txt->offsets || !txt->index)))
+        return fail(UMLH_E_INVALID, "%s: index/offsets required", who);
+    return UMLH_OK;
+}
+
+int umlh_train_steps_grouped(const umlh_group_item_t* items, int32_t n_items, int32_t n_steps, void* stream) {
+    if (!items || n_items < 1 || n_steps < 0) return fail(UMLH_E_INVALID, "umlh_train_steps_grouped: bad arguments");
+    MicroItem* mi = new (std::nothrow) MicroItem[n_items];
+    if (!mi) return fail(UMLH_E_INVALID, "umlh_train_steps_grouped: out of host memory");
+    bool all_micro = true;
+    int rc = UMLH_OK;
+    for (int i = 0; i < n_items && !rc; ++i) {
+        const umlh_group_item_t& g = items[i];
+        rc = check_streams(g.handle, g.img, g.txt, n_steps, g.lr, "umlh_train_steps_grouped");
+        if (rc) break;
+        if (g.handle->device != items[0].handle->device) { rc = fail(UMLH_E_INVALID, "umlh_train_steps_grouped: heads on different devices"); break; }
+        for (int j = 0; j < i; ++j)
+            if (items[j].handle == g.handle) rc = fail(UMLH_E_INVALID, "umlh_train_steps_grouped: a handle appears twice");
+        mi[i] = MicroItem{g.handle, g.img, g.txt, g.lr, g.first_step, g.alpha, g.img_alpha, g.scalars_out};
+        all_micro = all_micro && micro_eligible(g.handle, g.img, g.txt, n_steps);
+    }
+    if (!rc && n_steps > 0) {
+        DeviceGuard dg_(items[0].handle->device);
+        if (all_micro) {
+            rc = micro_run(mi, n_items, n_steps, (hipStream_t)stream);
+        } else {          // shapes outside the micro kernel's envelope: the heads step one after the other on the general path
+            for (int i = 0; i < n_items && !rc; ++i)
+                rc = umlh_train_steps(items[i].handle, items[i].img, items[i].txt, n_steps, items[i].lr, items[i].first_step,
+                                      items[i].alpha, items[i].img_alpha, items[i].scalars_out, stream);
+        }
+    }
+    delete[] mi;
+    return rc;
+}
+
 int umlh_train_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
                     float* scalars_out, void* stream) {
     int rc = check_step(h, img, txt, hy, "umlh_train_step");
@@ -896,6 +1151,10 @@ int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_strea
     if ((img && (!img->offsets || !img->index)) || (txt && (!txt->offsets || !txt->index)))
         return fail(UMLH_E_INVALID, "umlh_train_steps: index/offsets required");
     DeviceGuard dg_(h->device);
+    if (micro_eligible(h, img, txt, n_steps)) {       // batch <= 64 linear head: one persistent launch for all n_steps
+        MicroItem it{h, img, txt, lr, first_step, alpha, img_alpha, scalars_out};
+        return micro_run(&it, 1, n_steps, (hipStream_t)stream);
+    }
     for (int k = 0; k < n_steps; ++k) {
         umlh_batch_t bi, bt;
         memset(&bi, 0, sizeof(bi));

@@ -113,6 +113,52 @@ def _state_dict_cpu(model):
     return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
 
+def _state_dict_snapshot(model):
+    """Best-model snapshot (finetune.py:249) kept ON THE DEVICE: an asynchronous clone instead of a device-to-host copy
+    and a host sync at every evaluation point; it is moved to the CPU once, when train() returns it."""
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def _to_cpu(sd):
+    return {k: v.cpu() for k, v in sd.items()}
+
+
+def _check_micro(engine):
+    st = engine.micro_status()
+    if st != 0:
+        raise umlh.UmlhError(f"micro-step kernel gave up waiting at step {st - 1} of a call (another process starving the "
+                             "device of CUs?); the state of this head is undefined")
+
+
+def _block_end(i, max_iters, eval_freq):
+    """Last iteration of the block that starts at ``i``: the next evaluation point (or the final iteration)."""
+    return i if i % eval_freq == 0 else min(max_iters - 1, (i // eval_freq + 1) * eval_freq)
+
+
+def _draw_block(img_src, txt_src, n):
+    """Index batches of the next ``n`` steps of both loaders.  Consecutive batches inside both loaders' current epochs are
+    taken as ONE index slice each; a step at which a loader starts an epoch goes through next_index() -- image then
+    text, the reference's draw order (finetune.py:164-174) -- so the RNG protocol is untouched."""
+    bi = [] if img_src is not None else None
+    bt = [] if txt_src is not None else None
+    k = 0
+    while k < n:
+        span = min([n - k] + [src.remaining() for src in (img_src, txt_src) if src is not None])
+        if span == 0:
+            if img_src is not None:
+                bi.append(img_src.next_index())
+            if txt_src is not None:
+                bt.append(txt_src.next_index())
+            k += 1
+        else:
+            if img_src is not None:
+                bi.append(img_src.take_span(span))
+            if txt_src is not None:
+                bt.append(txt_src.take_span(span))
+            k += span
+    return bi, bt
+
+
 def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, scheduler, device="cuda",
           max_iters=1000, alpha=1.0, eval_freq=EVAL_FREQ, patience=5, capture_features_during_training=False,
           features_pth="./", args=None, logger=None, precision="fp32", diagnostics=None):
@@ -140,28 +186,9 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
         if blockwise:
             # all steps up to and including the next evaluation point in ONE C call:
             # no Python, no host sync between steps
-            i_end = i if i % eval_freq == 0 else min(max_iters - 1, (i // eval_freq + 1) * eval_freq)
+            i_end = _block_end(i, max_iters, eval_freq)
             n = i_end - i + 1
-            bi = [] if img_src is not None else None
-            bt = [] if txt_src is not None else None
-            k = 0
-            while k < n:
-                # consecutive batches inside both loaders' current epochs are taken as ONE index slice each; a step
-                # at which a loader starts an epoch goes through next_index() -- image then text, the reference's
-                # draw order (finetune.py:164-174) -- so the RNG protocol is untouched
-                span = min([n - k] + [src.remaining() for src in (img_src, txt_src) if src is not None])
-                if span == 0:
-                    if img_src is not None:
-                        bi.append(img_src.next_index())
-                    if txt_src is not None:
-                        bt.append(txt_src.next_index())
-                    k += 1
-                else:
-                    if img_src is not None:
-                        bi.append(img_src.take_span(span))
-                    if txt_src is not None:
-                        bt.append(txt_src.take_span(span))
-                    k += span
+            bi, bt = _draw_block(img_src, txt_src, n)
             lrs = scheduler.lr_table(n)
             engine.train_steps(img_src.table(precision) if img_src else None, bi,
                                txt_src.table(precision) if txt_src else None, bt, lrs,
@@ -192,12 +219,15 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
                         "train/txt_grad_norm": gd["txt_grad_norm"], "train/grad_agreement_rate": gd["grad_agreement_rate"],
                         "train/feature_direction_sim": feat_sim})
         if i % eval_freq == 0:
-            state_dict_cpu = _state_dict_cpu(model)
-            val_loss, val_acc = validate(model, val_loader, device=device)
+            state_dict_cpu = _state_dict_snapshot(model)          # device-side clone; moved to the CPU on return
+            model.eval()
+            res, (s,) = validate_many([(model, val_loader)] + ([(model, test_loader)] if test_loader is not None else []),
+                                      extra=[scalars[i]])
+            model.train()
+            val_loss, val_acc = res[0]
             testlog = ""
             if test_loader is not None:
-                _, test_acc = validate(model, test_loader, device=device)
-                testlog = f" | Test Acc: {test_acc:.4f}"
+                testlog = f" | Test Acc: {res[1][1]:.4f}"
             if out["val_acc"] is None or val_acc > out["val_acc"]:
                 out.update(iter=i, val_acc=val_acc, val_loss=val_loss, model=state_dict_cpu)
                 no_improve = 0
@@ -205,7 +235,8 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
                 no_improve += 1
             if logger is not None:
                 logger.log({"val/val_loss": val_loss, "val/val_acc": val_acc, "iter": i})
-            s = scalars[i].cpu()
+            if not bool(torch.isfinite(s).all()):
+                _check_micro(engine)
             print(f"Iter {i} | Img Loss: {s[umlh.S_LOSS_IMG]:.4f} | Text Loss: {s[umlh.S_LOSS_TXT]:.4f} | "
                   f"Img Acc: {s[umlh.S_ACC_IMG]:.4f} | Text Acc: {s[umlh.S_ACC_TXT]:.4f} | Val Loss: {val_loss:.4f} | "
                   f"Val Acc {val_acc:.4f}{testlog} | Count {no_improve}/{patience}")
@@ -213,7 +244,9 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
                 print(f"=> Early stopping at Iter {i}")
                 break
         i += 1
+    _check_micro(engine)
     model.load_state_dict(out["model"])
+    out["model"] = _to_cpu(out["model"])
     val_loss, val_acc = validate(model, val_loader, device=device)
     if logger is not None:
         logger.log({"val/best_val_loss": val_loss, "val/best_val_acc": val_acc, "iter": out["iter"]})
@@ -222,7 +255,142 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
     return out
 
 
+def train_grouped(runs, device="cuda", eval_freq=EVAL_FREQ, precision="fp32"):
+    """``train`` for MANY independent heads in lockstep: the grid points of a sweep (finetune.py:406-448) share the
+    feature tables and differ in hyper-parameters, seeds and batch orders.  Between two evaluation points all live heads
+    advance inside the same grouped persistent launches (``umlh_train_steps_grouped``); at an evaluation point every
+    head's validation / test passes are enqueued and read back with one host synchronisation.  Each head keeps the
+    exact semantics of ``train`` (evaluation cadence, strict-improvement best snapshot, patience, restored weights,
+    returned dict); ``runs`` = dicts with the arguments of ``train`` (model, image_loader, text_loader, val_loader,
+    test_loader, optimizer, scheduler, max_iters, alpha, patience)."""
+    st = []
+    for r in runs:
+        model = r["model"]
+        model.train()
+        assert r.get("image_loader") is not None or r.get("text_loader") is not None, "At least one of the loaders should be provided"
+        dev = model.head.weight.device
+        img_src = _RowSource(r["image_loader"], dev, "image", precision) if r.get("image_loader") is not None else None
+        txt_src = _RowSource(r["text_loader"], dev, "text", precision) if r.get("text_loader") is not None else None
+        if not all(src is None or src.indexed for src in (img_src, txt_src)):
+            raise umlh.UmlhError("train_grouped needs FeatureLoader inputs (device-resident tables)")
+        engine = model.fused_engine(r["optimizer"], max_rows_img=img_src.capacity if img_src else 32,
+                                    max_rows_txt=txt_src.capacity if txt_src else 32, precision=precision)
+        engine.enable_diagnostics(False)
+        st.append(dict(r, img_src=img_src, txt_src=txt_src, engine=engine, i=0, last_i=-1, no_improve=0, live=True,
+                       scalars=torch.zeros(r["max_iters"], umlh.N_SCALARS, dtype=torch.float32, device=dev),
+                       out={"iter": None, "val_acc": None, "model": None, "val_classwise": None, "val_loss": None,
+                            "model_records": []}))
+    while any(h["live"] for h in st):
+        # ---- one block per live head: all steps up to and including its next evaluation point ----
+        by_n = {}
+        for h in st:
+            if not h["live"]:
+                continue
+            i_end = _block_end(h["i"], h["max_iters"], eval_freq)
+            n = i_end - h["i"] + 1
+            bi, bt = _draw_block(h["img_src"], h["txt_src"], n)
+            opt, sch = h["optimizer"], h["scheduler"]
+            job = dict(engine=h["engine"], img_table=h["img_src"].table(precision) if h["img_src"] else None, img_index_batches=bi,
+                       txt_table=h["txt_src"].table(precision) if h["txt_src"] else None, txt_index_batches=bt,
+                       lrs=sch.lr_table(n), first_step=opt.step_count + 1, alpha=h["alpha"], img_alpha=1.0,
+                       scalars_out=h["scalars"][h["i"]:h["i"] + n])
+            by_n.setdefault(n, []).append(job)
+            opt.step_count += n
+            sch.step(sch.last_epoch + n)
+            h["i"] = h["last_i"] = i_end
+        for n, jobs in by_n.items():
+            umlh.train_steps_grouped(jobs, n)
+        # ---- evaluation points (every live head sits on one, or on its final iteration) ----
+        due = [h for h in st if h["live"] and h["i"] % eval_freq == 0]
+        if due:
+            pairs, extra = [], []
+            for h in due:
+                h["snap"] = _state_dict_snapshot(h["model"])
+                h["model"].eval()
+                pairs.append((h["model"], h["val_loader"]))
+                if h.get("test_loader") is not None:
+                    pairs.append((h["model"], h["test_loader"]))
+                extra.append(h["scalars"][h["i"]])
+            res, _ = validate_many(pairs, extra=extra)
+            k = 0
+            for h in due:
+                h["model"].train()
+                val_loss, val_acc = res[k]
+                k += 2 if h.get("test_loader") is not None else 1
+                out = h["out"]
+                if out["val_acc"] is None or val_acc > out["val_acc"]:
+                    out.update(iter=h["i"], val_acc=val_acc, val_loss=val_loss, model=h.pop("snap"))
+                    h["no_improve"] = 0
+                else:
+                    h["no_improve"] += 1
+                    h.pop("snap")
+                if h["no_improve"] >= h["patience"]:
+                    h["live"] = False                               # early stopping of this head
+        for h in st:
+            if h["live"]:
+                h["i"] += 1
+                if h["i"] >= h["max_iters"]:
+                    h["live"] = False
+    outs = []
+    for h in st:
+        _check_micro(h["engine"])
+        h["model"].load_state_dict(h["out"]["model"])
+        h["out"]["model"] = _to_cpu(h["out"]["model"])
+        h["out"]["train_scalars"] = h["scalars"][:h["last_i"] + 1].cpu()
+        outs.append(h["out"])
+    return outs
+
+
 EVAL_SLAB = 4096     # rows per forward launch of a whole-table evaluation
+
+
+def _slab_evaluable(loader):
+    return hasattr(loader, "iter_index") and not loader.shuffle and not loader.drop_last and len(loader.table) > 0
+
+
+def _eval_enqueue(model, val_loader):
+    """Enqueue the whole-table evaluation of an unshuffled ``FeatureLoader`` (one ``umlh_eval_rows`` launch per
+    4096-row slab) and return the device tensor of per-row {CE, correct} -- no host synchronisation."""
+    dev = model.head.weight.device
+    val_loader.iter_index()                       # iter(loader): the iterator's base seed is drawn as in the reference
+    t = val_loader.table
+    n = len(t)
+    stats = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    engine = model._infer_engine(min(n, EVAL_SLAB))
+    for s0 in range(0, n, EVAL_SLAB):
+        m = min(EVAL_SLAB, n - s0)
+        engine.eval_rows(umlh.RowBatch(t.features[s0:s0 + m], t.labels[s0:s0 + m]), stats[s0:s0 + m])
+    return stats
+
+
+def _eval_finish(stats_cpu, bs):
+    """(val_loss, val_acc) from per-row stats: mean over batches of the per-batch mean CE, global mean of correct."""
+    st = stats_cpu.double().numpy()
+    n = st.shape[0]
+    starts = list(range(0, n, bs))
+    val_loss = float(sum(st[s0:s0 + bs, 0].sum() / min(bs, n - s0) for s0 in starts) / len(starts))
+    return val_loss, float(st[:, 1].sum() / n)
+
+
+def validate_many(pairs, extra=None):
+    """``validate`` for several (model, loader) pairs with ONE host synchronisation: every evaluation is enqueued
+    first (``_eval_enqueue``), then all per-row statistics come back in a single device-to-host copy.  Used at the
+    evaluation points of ``train`` (val + test) and of the grouped sweep (every head's val + test).  ``extra``: device
+    float tensors (e.g. the step's scalar rows) that ride on the same copy; returns (results, extras on the CPU)."""
+    extra = list(extra or [])
+    if not all(_slab_evaluable(ld) for _, ld in pairs):
+        return [validate(m, ld) for m, ld in pairs], [e.cpu() for e in extra]
+    stats = [_eval_enqueue(m, ld) for m, ld in pairs]
+    flat = torch.cat([st.reshape(-1) for st in stats] + [e.reshape(-1).to(torch.float32) for e in extra]).cpu()
+    out, pos = [], 0
+    for (m, ld), st in zip(pairs, stats):
+        out.append(_eval_finish(flat[pos:pos + st.numel()].reshape(-1, 2), ld.batch_size))
+        pos += st.numel()
+    ex = []
+    for e in extra:
+        ex.append(flat[pos:pos + e.numel()].reshape(e.shape))
+        pos += e.numel()
+    return out, ex
 
 
 def validate(model, val_loader, device="cuda"):
@@ -236,21 +404,10 @@ def validate(model, val_loader, device="cuda"):
     dev = model.head.weight.device
     model.eval()
     src_indexed = hasattr(val_loader, "iter_index")
-    if src_indexed and not val_loader.shuffle and not val_loader.drop_last and len(val_loader.table) > 0:
-        val_loader.iter_index()                       # iter(loader): the iterator's base seed is drawn as in the reference
-        t = val_loader.table
-        n, bs = len(t), val_loader.batch_size
-        stats = torch.empty(n, 2, dtype=torch.float32, device=dev)
-        engine = model._infer_engine(min(n, EVAL_SLAB))
-        for s0 in range(0, n, EVAL_SLAB):
-            m = min(EVAL_SLAB, n - s0)
-            engine.eval_rows(umlh.RowBatch(t.features[s0:s0 + m], t.labels[s0:s0 + m]), stats[s0:s0 + m])
-        st = stats.cpu().double().numpy()
-        starts = list(range(0, n, bs))
-        val_loss = float(sum(st[s0:s0 + bs, 0].sum() / min(bs, n - s0) for s0 in starts) / len(starts))
-        val_acc = float(st[:, 1].sum() / n)
+    if _slab_evaluable(val_loader):
+        out = _eval_finish(_eval_enqueue(model, val_loader).cpu(), val_loader.batch_size)
         model.train()
-        return val_loss, val_acc
+        return out
     rows, slots = [], []
     it = val_loader.iter_index() if src_indexed else iter(val_loader)
     engine = None
@@ -418,6 +575,8 @@ def sweep(datasets, hyperparams, args):
     (reference :406-448); returns (results, best_val_acc, best_test_acc).
 
     ``args.sweep_workers > 1`` runs the grid points concurrently on one GPU (``sweep_farm``)."""
+    if getattr(args, "sweep_mode", "") == "grouped":
+        return sweep_grouped(datasets, hyperparams, args)
     if int(getattr(args, "sweep_workers", 1) or 1) > 1:
         return sweep_farm(datasets, hyperparams, args, int(args.sweep_workers))
     results = {"test_acc": [], "val_acc": [], "hparams": [], "model_records": []}
@@ -433,6 +592,75 @@ def sweep(datasets, hyperparams, args):
 def farm_seed(base_seed, idx):
     """Seed of grid point ``idx``'s private generator (loader orders) and of its model init."""
     return (int(base_seed) if base_seed is not None and int(base_seed) >= 0 else 0) * 100003 + 7919 * (idx + 1)
+
+
+def sweep_grouped(datasets, hyperparams, args):
+    """The sweep as ONE grouped job (``args.sweep_mode = "grouped"``): every grid point becomes a head of the same
+    persistent launches (``train_grouped`` / ``umlh_train_steps_grouped``), all reading the same device-resident
+    feature tables -- the [G, C, d] grouped multi-head farm of SURVEY 8(f) rank 2.  Like ``sweep_farm`` every point
+    draws its loader orders from a private generator seeded by ``farm_seed(args.seed, k)`` and initialises its model
+    under that seed, so a point's result is independent of which other points run beside it: it equals the isolated run
+    of that point (``setup_feature_run`` with the same generator) bit for bit."""
+    from engine.models.head import UML, UMLClip
+    points = _grid(hyperparams)
+    dev = torch.device(args.device)
+    precision = getattr(args, "precision", "fp32")
+    tables = feature_tables(datasets["img_tr"], datasets["img_val"], datasets["img_te"], datasets["text_ds"], dev)
+    if precision == "bf16":
+        for t in tables.values():
+            t.features_bf16()
+    d_img, d_txt = tables["train"].features.shape[1], tables["text"].features.shape[1]
+    text_indim = getattr(args, "text_indim", None) if args.modality == "crossmodal" else getattr(args, "common_dim", 0)
+    common_dim = 0 if args.modality == "crossmodal" else (text_indim or 0)
+    runs, slots = [], []
+    results = [None] * len(points)
+    for idx, hp in enumerate(points):
+        ckpt_dir = os.path.join(args.savepath, hparam_str(hp["optim"], hp["lr"], hp["weight_decay"], hp["batch_size"],
+                                                          hp["max_iter"], hp["dropout"], hp["learnable_temp"]))
+        os.makedirs(ckpt_dir, exist_ok=True)
+        test_path = os.path.join(ckpt_dir, "test_result.pth")
+        if os.path.exists(test_path) and not FLAG:
+            print(f"=> Skipping {ckpt_dir} as it already exists!")
+            results[idx] = torch.load(test_path, map_location="cpu", weights_only=True)
+            continue
+        torch.manual_seed(farm_seed(args.seed, idx))
+        if args.use_clip:
+            model = UMLClip(d_img, args.nclasses, logit_scale_init=args.logit, bias=False, learnable_temp=hp["learnable_temp"])
+        else:
+            tin = (d_txt if text_indim is None else text_indim) if args.modality == "crossmodal" else (text_indim or 0)
+            model = UML(d_img, tin, args.nclasses, bias=False, learnable_temp=hp["learnable_temp"])
+        model.to(dev)
+        if wants_zero_shot_init(args.classifier_init, args.modality, common_dim, d_txt):
+            model.zero_shot_init(datasets["text_ds"])
+        optimizer = build_optimizer(model.parameters(), hp["optim"], hp["lr"], hp["weight_decay"])
+        scheduler = build_lr_scheduler(optimizer, hp["lr_scheduler"], hp["warmup_iter"], hp["max_iter"],
+                                       warmup_type=hp["warmup_type"], warmup_lr=hp["warmup_min_lr"])
+        gen = torch.Generator()
+        gen.manual_seed(farm_seed(args.seed, idx))
+        kw = {"order_rng": getattr(args, "order_rng", "torch-cpu"), "generator": gen}
+        bs = hp["batch_size"]
+        image_loader = FeatureLoader(tables["train"], bs, shuffle=True, kind="image", **kw)
+        text_loader = FeatureLoader(tables["text"], bs, shuffle=True, kind="text", **kw)
+        if args.modality == "image":
+            text_loader = None
+        elif args.modality == "text":
+            image_loader = None
+        val_loader = FeatureLoader(tables["val"], bs, shuffle=False, kind="image", **kw)
+        test_loader = FeatureLoader(tables["test"], bs, shuffle=False, kind="image", **kw)
+        runs.append(dict(model=model, image_loader=image_loader, text_loader=text_loader, val_loader=val_loader,
+                         test_loader=test_loader if getattr(args, "eval_test", True) else None, optimizer=optimizer,
+                         scheduler=scheduler, max_iters=hp["max_iter"], alpha=args.alpha, patience=hp["patience"],
+                         final_test_loader=test_loader))
+        slots.append((idx, test_path))
+    outs = train_grouped(runs, device=dev, precision=precision)
+    finals, _ = validate_many([(r["model"], r["final_test_loader"]) for r in runs]) if runs else ([], [])
+    for (idx, test_path), out, (test_loss, test_acc) in zip(slots, outs, finals):
+        test_dict = {"test_acc": test_acc, "val_acc": out["val_acc"], "model": out["model"], "iter": out["iter"]}
+        torch.save(test_dict, test_path)
+        results[idx] = test_dict
+    res = {"test_acc": [o["test_acc"] for o in results], "val_acc": [o["val_acc"] for o in results],
+           "hparams": points, "model_records": []}
+    return _report(res, args)
 
 
 def sweep_farm(datasets, hyperparams, args, workers):

@@ -20,12 +20,12 @@ PREC_IDS = {"fp32": 0, "bf16": 1}
 N_CORE_SCALARS = 8
 N_SCALARS = 12
 
-SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_seq.hip", "umlh_kernels_enc.hip", "umlh_api.cpp"]
+SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_micro.hip", "umlh_kernels_seq.hip", "umlh_kernels_enc.hip", "umlh_api.cpp"]
 EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_eval_rows", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
-           "umlh_train_steps", "umlh_seq_mse_forward", "umlh_seq_mse_backward",
+           "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_seq_mse_forward", "umlh_seq_mse_backward",
            "umlh_random_permutation", "umlh_debug_buffer",
            "umlh_gemm_f32", "umlh_add_inplace", "umlh_bias_act", "umlh_relu_backward", "umlh_dropout", "umlh_colsum",
            "umlh_add_layernorm_forward", "umlh_layernorm_backward", "umlh_add_positions", "umlh_positions_backward",
@@ -60,6 +60,12 @@ class Stream(C.Structure):
                 ("offsets", C.POINTER(C.c_int32))]
 
 
+class GroupItem(C.Structure):
+    _fields_ = [("handle", C.c_void_p), ("img", C.POINTER(Stream)), ("txt", C.POINTER(Stream)),
+                ("lr", C.POINTER(C.c_double)), ("first_step", C.c_int64), ("alpha", C.c_float), ("img_alpha", C.c_float),
+                ("scalars_out", C.c_void_p)]
+
+
 class Hyper(C.Structure):
     _fields_ = [("lr", C.c_double), ("step", C.c_int64), ("alpha", C.c_float), ("img_alpha", C.c_float),
                 ("flags", C.c_int32), ("reserved", C.c_int32)]
@@ -73,7 +79,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """Cross-compile the HIP sources for gfx950 into umlh/libumlh.so (in-tree, so the
     binary travels with the repo snapshot to the GPU box)."""
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(_CSRC, "umlh_common.h"), os.path.join(_INCLUDE, "umlh.h")]
+    deps = srcs + [os.path.join(_CSRC, "umlh_common.h"), os.path.join(_CSRC, "umlh_micro.h"), os.path.join(_INCLUDE, "umlh.h")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -141,6 +147,9 @@ def load_library():
     lib.umlh_to_bf16.argtypes = [vp, vp, i64, vp]
     lib.umlh_train_steps.argtypes = [vp, C.POINTER(Stream), C.POINTER(Stream), i32, C.POINTER(C.c_double), i64,
                                      C.c_float, C.c_float, vp, vp]
+    lib.umlh_train_steps_grouped.argtypes = [C.POINTER(GroupItem), i32, i32, vp]
+    lib.umlh_micro_status.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.umlh_micro_launches.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.umlh_seq_mse_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.umlh_seq_mse_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.umlh_random_permutation.argtypes = [i64, u64, vp, vp]

@@ -189,6 +189,41 @@ class HeadEngine:
                                        self._stream()), "umlh_train_step")
         return so
 
+    def _make_stream(self, table, batches, dim, cap, n):
+        """(ctypes Stream, keep-alive tuple) of one modality for ``n`` steps; see ``train_steps``."""
+        if table is None:
+            return None, None
+        f, y = table[0], table[1]
+        f16 = table[2] if len(table) > 2 else None
+        if f.dtype != torch.float32 or not f.is_contiguous() or f.shape[1] != dim or y.dtype != torch.int64:
+            raise UmlhError("train_steps: table must be contiguous fp32 [N,dim] + int64 labels")
+        if self.precision == "bf16" and (f16 is None or f16.dtype != torch.bfloat16 or f16.shape != f.shape):
+            raise UmlhError("train_steps: bf16 engine needs the table's bf16 shadow")
+        # an entry is one step's index vector, or (index slice, [sizes]) covering several consecutive steps
+        parts, sizes = [], []
+        for b in batches:
+            if isinstance(b, tuple):
+                parts.append(b[0])
+                sizes.extend(int(z) for z in b[1])
+            else:
+                parts.append(b)
+                sizes.append(int(b.numel()))
+        if len(sizes) != n:
+            raise UmlhError("train_steps: one index vector per step required")
+        if max(sizes) > cap:
+            raise UmlhError(f"train_steps: batch of {max(sizes)} rows exceeds capacity {cap}")
+        idx = torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
+        if idx.numel() != sum(sizes):
+            raise UmlhError("train_steps: index slices do not match their batch sizes")
+        offs = (C.c_int32 * (n + 1))()
+        acc = 0
+        for k, sz in enumerate(sizes):
+            offs[k] = acc
+            acc += sz
+        offs[n] = acc
+        keep = (f, y, f16, idx, offs)
+        return Stream(_ptr(f), _ptr(f16), _ptr(y), _ptr(idx), offs), keep
+
     def train_steps(self, img_table, img_index_batches, txt_table, txt_index_batches, lrs, first_step: int,
                     alpha: float = 1.0, img_alpha: float = 1.0, scalars_out: Optional[torch.Tensor] = None) -> None:
         """``len(lrs)`` consecutive fused steps with no Python in between (umlh_train_steps).
@@ -196,43 +231,8 @@ class HeadEngine:
         = one int64 device index vector per step, or (index slice, [batch sizes]) entries that each cover
         several consecutive steps."""
         n = len(lrs)
-
-        def stream(table, batches, dim, cap):
-            if table is None:
-                return None, None
-            f, y = table[0], table[1]
-            f16 = table[2] if len(table) > 2 else None
-            if f.dtype != torch.float32 or not f.is_contiguous() or f.shape[1] != dim or y.dtype != torch.int64:
-                raise UmlhError("train_steps: table must be contiguous fp32 [N,dim] + int64 labels")
-            if self.precision == "bf16" and (f16 is None or f16.dtype != torch.bfloat16 or f16.shape != f.shape):
-                raise UmlhError("train_steps: bf16 engine needs the table's bf16 shadow")
-            # an entry is one step's index vector, or (index slice, [sizes]) covering several consecutive steps
-            parts, sizes = [], []
-            for b in batches:
-                if isinstance(b, tuple):
-                    parts.append(b[0])
-                    sizes.extend(int(z) for z in b[1])
-                else:
-                    parts.append(b)
-                    sizes.append(int(b.numel()))
-            if len(sizes) != n:
-                raise UmlhError("train_steps: one index vector per step required")
-            if max(sizes) > cap:
-                raise UmlhError(f"train_steps: batch of {max(sizes)} rows exceeds capacity {cap}")
-            idx = torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
-            if idx.numel() != sum(sizes):
-                raise UmlhError("train_steps: index slices do not match their batch sizes")
-            offs = (C.c_int32 * (n + 1))()
-            acc = 0
-            for k, sz in enumerate(sizes):
-                offs[k] = acc
-                acc += sz
-            offs[n] = acc
-            keep = (f, y, f16, idx, offs)
-            return Stream(_ptr(f), _ptr(f16), _ptr(y), _ptr(idx), offs), keep
-
-        si, keep_i = stream(img_table, img_index_batches, self.d_img, self.cfg.max_rows_img)
-        st, keep_t = stream(txt_table, txt_index_batches, self.d_shared, self.cfg.max_rows_txt)
+        si, keep_i = self._make_stream(img_table, img_index_batches, self.d_img, self.cfg.max_rows_img, n)
+        st, keep_t = self._make_stream(txt_table, txt_index_batches, self.d_shared, self.cfg.max_rows_txt, n)
         lr_arr = (C.c_double * n)(*[float(x) for x in lrs])
         lock = ENQUEUE_LOCK
         if lock is not None:
@@ -246,6 +246,18 @@ class HeadEngine:
         check(rc, "umlh_train_steps")
         # index tensors must outlive the enqueued kernels: keep them until the next call
         self._keepalive = (keep_i, keep_t)
+
+    def micro_launches(self) -> int:
+        """Persistent micro-step launches this engine has taken part in."""
+        v = C.c_int64(0)
+        check(self.lib.umlh_micro_launches(self.handle, C.byref(v)), "umlh_micro_launches")
+        return int(v.value)
+
+    def micro_status(self) -> int:
+        """0, or 1 + the step at which a bounded in-launch wait of the micro-step kernel gave up (host sync)."""
+        v = C.c_int32(0)
+        check(self.lib.umlh_micro_status(self.handle, C.byref(v)), "umlh_micro_status")
+        return int(v.value)
 
     def grad_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], alpha: float = 1.0,
                   img_alpha: float = 1.0, weights_unchanged: bool = False) -> torch.Tensor:
@@ -321,6 +333,34 @@ class HeadEngine:
         so = scalars_out if scalars_out is not None else self._scalars
         check(self.lib.umlh_eval_batch(self.handle, self._ref(b), _ptr(so), self._stream()), "umlh_eval_batch")
         return so
+
+
+def train_steps_grouped(jobs, n_steps: int) -> None:
+    """``n_steps`` fused steps of MANY heads in grouped persistent launches (``umlh_train_steps_grouped``): the
+    reference's sweep over a HYPER_DICT grid (finetune.py:406-448) as one [G, C, d] job.  ``jobs`` is a list of dicts
+    with the keyword arguments of ``HeadEngine.train_steps`` plus ``engine``; all engines live on one device and the
+    launches go to that device's current stream.  Bit-identical to calling ``train_steps`` on each engine."""
+    if not jobs:
+        return
+    from ._lib import GroupItem
+    items = (GroupItem * len(jobs))()
+    keep = []
+    for j, job in enumerate(jobs):
+        e = job["engine"]
+        lrs = job["lrs"]
+        if len(lrs) != n_steps:
+            raise UmlhError("train_steps_grouped: every head needs n_steps learning rates")
+        si, ki = e._make_stream(job.get("img_table"), job.get("img_index_batches"), e.d_img, e.cfg.max_rows_img, n_steps)
+        st, kt = e._make_stream(job.get("txt_table"), job.get("txt_index_batches"), e.d_shared, e.cfg.max_rows_txt, n_steps)
+        lr_arr = (C.c_double * n_steps)(*[float(x) for x in lrs])
+        so = job.get("scalars_out")
+        items[j] = GroupItem(e.handle, C.pointer(si) if si is not None else None, C.pointer(st) if st is not None else None,
+                             lr_arr, int(job["first_step"]), float(job.get("alpha", 1.0)), float(job.get("img_alpha", 1.0)),
+                             _ptr(so))
+        keep.append((si, st, ki, kt, lr_arr, so))
+        e._keepalive = (ki, kt)
+    e0 = jobs[0]["engine"]
+    check(e0.lib.umlh_train_steps_grouped(items, len(jobs), int(n_steps), e0._stream()), "umlh_train_steps_grouped")
 
 
 def grad_diagnostics(scalars, n_elements: int, rows_img: int = 1, rows_txt: int = 1) -> dict:
