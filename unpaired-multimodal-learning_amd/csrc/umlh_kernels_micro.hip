@@ -13,9 +13,11 @@
 //      all records with sc1 loads (MI355X guide, Guideline 16 / "Valid forms", row 1) and merges them with the
 //      online-softmax rule -- the only cross-workgroup exchange of a step;
 //   3. dZ^T -> LDS, dW_slice = dZ^T X on the MFMA, the optimizer update of the slice straight from the accumulators.
-// The feature rows of a step are gathered by LDS-DMA (global_load_lds_dwordx4, per-lane source address = row gather)
-// into a ring of K-chunk buffers that runs ahead across phases and steps; the image is XOR-swizzled on the SOURCE
-// side (slot ^= row & 15) so that the forward's and the backward's ds_read_b128 are both conflict-free.
+// The feature rows of a step are gathered through registers (16-byte loads with per-lane row addresses, written to a
+// double-buffered LDS image one K-chunk later: the loads of chunk q+2 are in flight while chunk q feeds the MFMAs),
+// across phases and steps; the image is XOR-swizzled (slot ^= row & 15) so that the forward's ds_read_b128 and the
+// backward's ds_read_b32 are conflict-free.  (An LDS-DMA ring was measured first: each global_load_lds costs the
+// issuing wave ~100 cycles, eight per chunk as much as the chunk's whole MFMA time with one wave per SIMD.)
 //
 // All workgroups of a launch must be co-resident (spin waits): the host launches at most one workgroup per CU and
 // chains micro launches of one process on one device; every spin is bounded and reports through a status word.
@@ -24,8 +26,6 @@
 #include <type_traits>
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 namespace {
 
@@ -36,9 +36,6 @@ constexpr int LDZ = 66;            // dZ^T row stride (floats): banks 2*class + 
 __device__ __forceinline__ void wg_barrier() {
     // LDS writes of every wave visible before any wave passes; does NOT drain the LDS-DMA ring (no vmcnt wait)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 __device__ __forceinline__ void store_granule(unsigned long long* p, unsigned epoch, float v) {   // ONE aligned 8-B sc1 store
     __hip_atomic_store(p, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -101,29 +98,27 @@ struct MicroCfg {
     static constexpr int LDW = D + 8;                       // W slice row stride: b128 reads of 16 rows conflict-free (LDW % 64 == 8)
     static constexpr int SLOTS = CW / 4;                    // 16-B slots per row of a chunk
     static constexpr int SM = SLOTS - 1 < 15 ? SLOTS - 1 : 15;   // swizzle mask
-    static constexpr int DPW = CW / 16;                     // LDS-DMA instructions per wave per chunk (1 KiB each)
+    static constexpr int DPW = CW / 16;                     // 16-byte pieces per lane per chunk (64 rows x CW floats over 256 lanes)
     static constexpr int XBYTES = MROWS * CW * 4;
     static constexpr int WBYTES = CS * LDW * 4;
-    static constexpr int MISC = CS * LDZ * 4 + 2 * MROWS * 8 + 2 * MROWS * 4 + 4 * MROWS * 5 * 4 + 64 * 4 + 1024;
-    static constexpr int NBUF3_OK = WBYTES + 3 * XBYTES + MISC <= 160 * 1024;
-    static constexpr int NBUF = (NCH >= 2 && NBUF3_OK) ? 3 : 2;
-    static constexpr int SMEM = WBYTES + NBUF * XBYTES + MISC;
+    static constexpr int MISC = CS * LDZ * 4 + 2 * MROWS * 8 + 2 * MROWS * 4 + 4 * MROWS * 5 * 4 + 64 * 4;
+    static constexpr int SMEM = WBYTES + 2 * XBYTES + MISC;
     static constexpr int U = CW >= 64 ? CW / 64 : 1;        // 64-column blocks per chunk in the dW phase
+    static constexpr int NP = 2 * NCH;                      // chunk positions of a step: NCH forward, NCH backward
 };
 
 template <int NCH, int CW>
 __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* __restrict__ heads, int n_heads, int n_steps) {
     using K = MicroCfg<NCH, CW>;
-    constexpr int D = K::D, LDW = K::LDW, SM = K::SM, DPW = K::DPW, NBUF = K::NBUF, U = K::U;
+    constexpr int D = K::D, LDW = K::LDW, SM = K::SM, DPW = K::DPW, U = K::U, NP = K::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Wl = reinterpret_cast<float*>(smem);                                    // [CS][LDW]
-    float* Xb = reinterpret_cast<float*>(smem + K::WBYTES);                        // [NBUF][64][CW]
-    float* dzT = reinterpret_cast<float*>(smem + K::WBYTES + NBUF * K::XBYTES);    // [CS][LDZ]
+    float* Xb = reinterpret_cast<float*>(smem + K::WBYTES);                        // [2][64][CW]
+    float* dzT = reinterpret_cast<float*>(smem + K::WBYTES + 2 * K::XBYTES);       // [CS][LDZ]
     unsigned long long* rowbase = reinterpret_cast<unsigned long long*>(dzT + CS * LDZ);   // [2][64] byte address of the row
     int* labs = reinterpret_cast<int*>(rowbase + 2 * MROWS);                        // [2][64]
     float* red = reinterpret_cast<float*>(labs + 2 * MROWS);                        // [4 parts][64][5]
     float* misc = red + 4 * MROWS * 5;                                              // [64]: per-tile scalar partials, abort flag
-    float* dump = misc + 64;                                                        // [4 waves][64]: landing zone of the L2 prefetch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s16 = lane & 15, g = lane >> 4;
@@ -166,16 +161,17 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
     float msc[2] = {0.f, 0.f}, vsc[2] = {0.f, 0.f};
     if (learn) { msc[0] = H.m_scales[0]; msc[1] = H.m_scales[1]; vsc[0] = H.v_scales[0]; vsc[1] = H.v_scales[1]; }
 
-    // ---- row tables of a step: threads 0..63 own one row slot each ----
-    // slot -> (modality, local row): image tiles first, then text tiles; padding slots re-read a valid row (masked later)
-    // step offsets: a rolling window off[mod][j] = offs[mod][k + j], j = 0..2, advanced once per step (one load per
-    // modality per step, issued a step ahead), so that row counts never cost a memory round trip.  `rel` (0 = the
-    // current step, 1 = the next) is a literal at every call site: the window stays in registers.
-    int off[2][3];
+    // ---- row tables: threads 0..63 own one row slot each.  slot -> (modality, local row): image tiles first, then text
+    // tiles; padding slots re-read a valid row (masked later).  The table of step k+2 is built during step k (row ids
+    // requested at the top of the step, labels after the forward), so a step starts with its own and the next step's
+    // tables in LDS and the feature loads can run across the step boundary.
+    // Step offsets: a rolling window off[mod][j] = offs[mod][k + j], j = 0..3, advanced once per step (one load per
+    // modality per step, a step ahead).  `rel` is a literal at every call site: the window stays in registers.
+    int off[2][4];
 #pragma unroll
     for (int md = 0; md < 2; ++md)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) off[md][j] = H.offs[md] ? H.offs[md][j < n_steps ? j : n_steps] : 0;
+        for (int j = 0; j < 4; ++j) off[md][j] = H.offs[md] ? H.offs[md][j < n_steps ? j : n_steps] : 0;
     auto rows_of = [&](int rel, int mod) -> int { return off[mod][rel + 1] - off[mod][rel]; };
     long long rid_next = 0;
     auto fetch_rid = [&](int rel) {                         // issue the row-id load of step k + rel for this thread's slot
@@ -200,95 +196,106 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
         lab_next = valid ? (int)H.labels[mod][rid_next] : -1;
     };
     auto publish_labels = [&](int k) { labs[(k & 1) * MROWS + tid] = lab_next; };
-    if (tid < MROWS) { fetch_rid(0); publish_rowbase(0, 0); publish_labels(0); }
+    if (tid < MROWS) {
+        fetch_rid(0); publish_rowbase(0, 0); publish_labels(0);
+        if (n_steps > 1) { fetch_rid(1); publish_rowbase(1, 1); publish_labels(1); }
+    }
     wg_barrier();
 
-    // ---- LDS-DMA ring over (step, phase, chunk) ----
-    const long long total_q = (long long)n_steps * 2 * NCH;
-    // A chunk's DMAs are PREPARED right after the ring barrier (source addresses: the row-base reads cannot move across
-    // an LDS-DMA, which writes LDS) and ISSUED one by one between the MFMAs of the chunk being computed: an LDS-DMA
-    // costs the wave ~100 issue cycles, eight of them per chunk as much as the chunk's whole MFMA time.
-    struct Dma { const float* src[DPW]; float* buf; bool live; };
-    auto dma_prep = [&](long long q) -> Dma {
-        Dma dm;
-        dm.live = q < total_q;
-        const long long qq = dm.live ? q : 0;
-        const int step = (int)(qq / (2 * NCH)), c = (int)(qq % NCH);
-        dm.buf = Xb + (size_t)(qq % NBUF) * (MROWS * CW);
-        const unsigned long long* rb = rowbase + (step & 1) * MROWS;
+    // ---- feature rows: global -> registers -> LDS, one chunk (64 rows x CW floats) per position ----
+    // piece i of this lane: 16-byte slot o16 = (wave*DPW + i)*64 + lane of the chunk image = (row, slot p); it is READ from
+    // slot p ^ (row & SM) of the source row (the swizzle) and written linearly
+    const float* rowp_cur[DPW];
+    const float* rowp_nxt[DPW];
+    int soff[DPW], doff[DPW];
 #pragma unroll
-        for (int i = 0; i < DPW; ++i) {
-            const int o16 = (wave * DPW + i) * 64 + lane;           // 16-B slot number inside the chunk image
-            const int row = o16 / K::SLOTS, p = o16 % K::SLOTS;
-            dm.src[i] = reinterpret_cast<const float*>(rb[row]) + c * CW + 4 * (p ^ (row & SM));
-        }
-        return dm;
-    };
-    auto dma_one = [&](const Dma& dm, int i) {
-        if (dm.live) __builtin_amdgcn_global_load_lds((gptr_t)dm.src[i], (lptr_t)(dm.buf + (size_t)(wave * DPW + i) * 256), 16, 0, 0);
-    };
-    auto issue = [&](long long q) {                         // whole chunk at once (prologue)
-        const Dma dm = dma_prep(q);
+    for (int i = 0; i < DPW; ++i) {
+        const int o16 = (wave * DPW + i) * 64 + lane;
+        const int row = o16 / K::SLOTS, p = o16 % K::SLOTS;
+        soff[i] = 4 * (p ^ (row & SM));
+        doff[i] = 4 * o16;
+        rowp_cur[i] = reinterpret_cast<const float*>(rowbase[row]);
+        rowp_nxt[i] = rowp_cur[i];
+    }
+    f32x4m xr[DPW];
+    auto xload = [&](const float* const (&rowp)[DPW], int c) {
 #pragma unroll
-        for (int i = 0; i < DPW; ++i) dma_one(dm, i);
+        for (int i = 0; i < DPW; ++i) xr[i] = *reinterpret_cast<const f32x4m*>(rowp[i] + c * CW + soff[i]);
     };
-    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    const bool stamping = H.stamps != nullptr;
-#define MSTAMP(i) do { if (stamping) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; } } while (0)
-    auto ring_step = [&](long long q) -> Dma {              // chunk q landed everywhere; the buffer freed by chunk q-1 is refilled
-        MSTAMP(11);                                         // by the DMAs the caller issues between its MFMAs
-        if (q + NBUF - 1 <= total_q) wait_vm<(NBUF - 2) * DPW>(); else wait_vm<0>();
-        MSTAMP(7);
-        wg_barrier();
-        MSTAMP(8);
-        const Dma dm = dma_prep(q + NBUF - 1);
-        MSTAMP(10);
-        return dm;
-    };
+    auto xstore = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < NBUF - 1; ++q) issue(q);
+        for (int i = 0; i < DPW; ++i) *reinterpret_cast<f32x4m*>(Xb + buf * (MROWS * CW) + doff[i]) = xr[i];
+    };
+    // prologue: position 0 of step 0 into buffer 0, position 1 into the registers
+    xload(rowp_cur, 0);
+    xstore(0);
+    xload(rowp_cur, 1 % NCH);
+    wg_barrier();
 
+    constexpr int NOPT = (int)(sizeof(OptArgs) / 4);
+    float opt_pre[NOPT];
+    {
+        const float* op = reinterpret_cast<const float*>(H.opt);
+#pragma unroll
+        for (int i = 0; i < NOPT; ++i) opt_pre[i] = op[i];
+    }
     const unsigned epoch0 = H.epoch0;
     bool aborted = false;
     // phase stamps (diagnostic runs only; the values go to a buffer nothing else reads)
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool stamping = H.stamps != nullptr;
+#define MSTAMP(i) do { if (stamping) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; } } while (0)
     if (stamping) tprev = __builtin_readcyclecounter();
     for (int k = 0; k < n_steps && !aborted; ++k) {
+        const bool more = k + 1 < n_steps;
         const int ri = rows_of(0, 0), rt = rows_of(0, 1);
         const int ti = (ri + 15) >> 4, tt = (rt + 15) >> 4;
         const int mod = wave < ti ? 0 : 1;                               // modality of this wave's sample tile
         const bool tile_live = wave < ti + tt;
         const int local = mod == 0 ? 16 * wave + s16 : 16 * (wave - ti) + s16;
         const bool valid = tile_live && local < (mod == 0 ? ri : rt);
-        const int* lb = labs + (k & 1) * MROWS;
-        const int lab = lb[16 * wave + s16];
-        if (tid < MROWS && k + 1 < n_steps) fetch_rid(1);
+        const int lab = labs[(k & 1) * MROWS + 16 * wave + s16];
+        if (tid < MROWS && k + 2 < n_steps) fetch_rid(2);
         if (tid == 0) misc[63] = 0.f;                       // abort flag of this step (read after the gather's barrier)
-        // the step's optimizer scalars, made provably wave-uniform (scalar registers, scalar branches)
+        if (more) {                                         // the next step's row pointers (its table was finished a step ago)
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) rowp_nxt[i] = reinterpret_cast<const float*>(rowbase[((k + 1) & 1) * MROWS + ((wave * DPW + i) * 64 + lane) / K::SLOTS]);
+        }
+        // the step's optimizer scalars (requested one step ahead), made provably wave-uniform: scalar registers, scalar branches
         OptArgs o;
         {
-            const float* op = reinterpret_cast<const float*>(H.opt + k);
-            float tmp[sizeof(OptArgs) / 4];
+            float tmp[NOPT];
 #pragma unroll
-            for (int i = 0; i < (int)(sizeof(OptArgs) / 4); ++i) tmp[i] = op[i];
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(OptArgs) / 4); ++i) tmp[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tmp[i])));
+            for (int i = 0; i < NOPT; ++i) tmp[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(opt_pre[i])));
             __builtin_memcpy(&o, tmp, sizeof(OptArgs));
+            const float* op = reinterpret_cast<const float*>(H.opt + (more ? k + 1 : k));
+#pragma unroll
+            for (int i = 0; i < NOPT; ++i) opt_pre[i] = op[i];
         }
         const int okind = __builtin_amdgcn_readfirstlane(H.opt_kind);
-        int off_next[2];                                    // offs[k + 3]: enters the window at the end of this step
+        int off_next[2];                                    // offs[k + 4]: enters the window at the end of this step
 #pragma unroll
-        for (int md = 0; md < 2; ++md) off_next[md] = H.offs[md] ? H.offs[md][k + 3 < n_steps ? k + 3 : n_steps] : 0;
-        const long long q0 = (long long)k * 2 * NCH;
-
+        for (int md = 0; md < 2; ++md) off_next[md] = H.offs[md] ? H.offs[md][k + 4 < n_steps ? k + 4 : n_steps] : 0;
         MSTAMP(0);
+
+        // Position p of the step (chunk p is complete in LDS buffer p & 1): write chunk p+1 (in the registers) to the other
+        // buffer -- its last readers passed the barrier that ended position p-1 -- and request chunk p+2.
+        auto stage = [&](int p) {
+            if (p + 1 < NP || more) xstore((p + 1) & 1);
+            if (p + 2 < NP) xload(rowp_cur, (p + 2) % NCH);
+            else if (more) xload(rowp_nxt, (p + 2 - NP) % NCH);
+            __builtin_amdgcn_sched_barrier(0);              // the requests stay ahead of the position's MFMAs
+        };
+
         // ================= forward: raw[class 4g+r][sample s16 of tile `wave`] =================
         f32x4m acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const Dma dm = ring_step(q0 + c);
-            constexpr int T = CW / 16;                      // k-steps of the chunk == DMAs per wave (DPW)
+            stage(c);
+            MSTAMP(7);
+            constexpr int T = CW / 16;
             if (tile_live) {
-                const float* xrow = Xb + (size_t)((q0 + c) % NBUF) * (MROWS * CW) + (16 * wave + s16) * CW;
+                const float* xrow = Xb + (c & 1) * (MROWS * CW) + (16 * wave + s16) * CW;
                 const float* wrow = Wl + s16 * LDW + c * CW + 4 * g;
                 // one wave per SIMD: nothing but this wave's own earlier loads can hide the LDS latency, so the operand
                 // reads run two k-steps ahead of their MFMAs through a ring of three register sets
@@ -309,18 +316,17 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][1], b4[sl][1], acc1, 0, 0, 0);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][2], b4[sl][2], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][3], b4[sl][3], acc1, 0, 0, 0);
-                    dma_one(dm, t);                         // behind this k-step's MFMAs (the matrix pipe runs meanwhile)
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < DPW; ++i) dma_one(dm, i);
             }
+            MSTAMP(1);
+            wg_barrier();
+            MSTAMP(8);
         }
-        MSTAMP(1);
-        // next step's row table: the row ids were requested at the top of the step; the label load they feed is issued
-        // here and consumed after the gather
-        if (tid < MROWS && k + 1 < n_steps) publish_rowbase(1, k + 1);
+        asm volatile("s_nop 7" ::: "memory");              // see the note at the dW chain: result latency of the last MFMA
+        // next-but-one step's row table: the row ids were requested at the top of the step; the label load they feed is
+        // issued here and consumed after the gather.  (Parity k & 1: this step's own table is no longer read.)
+        if (tid < MROWS && k + 2 < n_steps) publish_rowbase(2, k + 2);
         // ---- slice-local softmax statistics of this lane's sample ----
         const float sc = scale[mod];
         const float NEG_INF = -__builtin_huge_valf();
@@ -410,20 +416,9 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             float* rp = red + (part * MROWS + smp) * 5;
             rp[0] = M; rp[1] = S; rp[2] = RY; rp[3] = __int_as_float(AM); rp[4] = SR;
         }
-        if (tid < MROWS && k + 1 < n_steps) publish_labels(k + 1);
+        if (tid < MROWS && k + 2 < n_steps) publish_labels(k + 2);
         wg_barrier();
         if (misc[63] != 0.f) { aborted = true; break; }
-        // L2 warm-up of the NEXT step's rows: one 4-byte LDS-DMA per 128-byte line into a dump zone (no register
-        // destination, nothing waits for it).  The ring's gathers of the next step then hit this XCD's L2 instead of
-        // paying the Infinity-Cache / HBM latency with only two chunks in flight.
-        if (k + 1 < n_steps) {
-            constexpr int LPR = D * 4 / 128 > 0 ? D * 4 / 128 : 1;       // 128-byte lines per row
-            const unsigned long long* rbn = rowbase + ((k + 1) & 1) * MROWS;
-            for (int L = tid; L < MROWS * LPR; L += 256) {
-                const float* src = reinterpret_cast<const float*>(rbn[L / LPR]) + (L % LPR) * 32;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dump + wave * 64), 4, 0, 0);
-            }
-        }
         MSTAMP(3);
         float M = NEG_INF, S = 0.f, RY = 0.f, SR = 0.f;
         int AM = 0x7fffffff;
@@ -446,7 +441,7 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
         const float w_over_rows = wmod / (float)(mod == 0 ? ri : rt);
         const float coef = valid ? w_over_rows * sc : 0.f;
         {
-            const float f = tile_live ? expf(mloc - M) / S : 0.f;
+            const float f = tile_live ? expf(mloc - M) * __builtin_amdgcn_rcpf(S) : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cls = c0 + 4 * g + r;
@@ -487,19 +482,49 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
         float af[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) af[m] = dzT[s16 * LDZ + 4 * m + g];
-
         MSTAMP(5);
+
         // ================= backward + update: dW[class 4g+r][column], straight into the optimizer =================
+        // (Issuing the optimizer arithmetic of chunk c-1 between the MFMAs of chunk c was measured and bought nothing: the
+        // f32-input MFMA runs at the f32 vector rate, the two compete for the same issue slots.)
+        auto wptr = [&](int c) -> float* { return Wl + (4 * g) * LDW + c * CW + (colok ? colw : 0); };
+        auto upd_math = [&](auto kind, int c, const f32x4m (&dacc)[U], float (&pw)[U][4]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    opt_update_fast<decltype(kind)::value>(o, inv_bc2, dacc[u][r], pw[u][r], mreg[c][u][r], vreg[c][u][r]);
+        };
+        auto w_read = [&](int c, float (&pw)[U][4]) {
+            const float* wp0 = wptr(c);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[u][r] = wp0[r * LDW + 64 * u];
+        };
+        auto w_write = [&](int c, const float (&pw)[U][4]) {       // rows >= C and (CW < 64) lanes without a column keep the padding:
+            float* wp0 = wptr(c);                                   // their stores go to a dump word (branch-free)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* dst = (c0 + 4 * g + r < C && colok) ? wp0 + r * LDW + 64 * u : misc + 32;
+                    *dst = pw[u][r];
+                }
+        };
+        // the optimizer kind is decided ONCE around the whole phase (straight-line code inside)
+        auto dw_phase = [&](auto kind) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const Dma dm = ring_step(q0 + NCH + c);
-            const float* xb = Xb + (size_t)((q0 + NCH + c) % NBUF) * (MROWS * CW);
+            stage(NCH + c);
+            MSTAMP(10);
+            const float* xb = Xb + ((NCH + c) & 1) * (MROWS * CW);
             f32x4m dacc[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) dacc[u] = f32x4m{0.f, 0.f, 0.f, 0.f};
-            // all B operands of the chunk first (16 U independent LDS reads in flight), then the MFMA chains with the
-            // next chunk's DMAs issued between them.  Lane s16 of wave w owns column 64u + 16w + s16: consecutive lanes
-            // read consecutive dwords of a row (the slot swizzle keeps the four rows of a k-step on different banks).
+            // all B operands of the chunk first (16 U independent LDS reads in flight), then the MFMA chains.  Lane s16 of
+            // wave w owns column 64u + 16w + s16: consecutive lanes read consecutive dwords of a row (the slot swizzle
+            // keeps the four rows of a k-step on different banks).
             float bq[16][U];
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
@@ -510,44 +535,31 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
                     bq[m][u] = xb[row * CW + 4 * ((col >> 2) ^ (row & SM)) + (col & 3)];
                 }
             }
+            float pw[U][4];
+            w_read(c, pw);
             __builtin_amdgcn_sched_barrier(0);              // reads stay ahead of the MFMA chains
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
+            for (int m = 0; m < 16; ++m)
 #pragma unroll
                 for (int u = 0; u < U; ++u) dacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bq[m][u], dacc[u], 0, 0, 0);
-                if (DPW >= 16 ? true : ((m + 1) % (16 / DPW) == 0)) {
-#pragma unroll
-                    for (int i = 0; i < (DPW >= 16 ? DPW / 16 : 1); ++i) dma_one(dm, DPW >= 16 ? m * (DPW / 16) + i : (m + 1) / (16 / DPW) - 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (stamping) { asm volatile("" :: "v"(dacc[0][0])); MSTAMP(9); }
-            // update of this thread's 4U elements: all weight reads, then the arithmetic, then all writes (an interleaved
-            // read-modify-write chain costs one LDS round trip per element with a single wave per SIMD).  Rows >= C and,
-            // for CW < 64, lanes without a column compute on the zero padding and are not written back.
-            float* wp0 = Wl + (4 * g) * LDW + c * CW + (colok ? colw : 0);
-            float pw[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pw[u][r] = wp0[r * LDW + 64 * u];
-            auto upd = [&](auto kind) {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        opt_update_fast<decltype(kind)::value>(o, inv_bc2, dacc[u][r], pw[u][r], mreg[c][u][r], vreg[c][u][r]);
-            };
-            if (okind == UMLH_OPT_ADAMW) upd(std::integral_constant<int, UMLH_OPT_ADAMW>{});
-            else if (okind == UMLH_OPT_ADAM) upd(std::integral_constant<int, UMLH_OPT_ADAM>{});
-            else upd(std::integral_constant<int, UMLH_OPT_SGD>{});
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + 4 * g + r < C && colok) wp0[r * LDW + 64 * u] = pw[u][r];
+            // The update reads the accumulators right behind the last MFMA of the chain.  hipcc (ROCm 7.2) pads that read
+            // with `s_nop 8`; on gfx950 v_mfma_f32_16x16x4_f32 has a 40-cycle result latency and the LAST accumulator
+            // register came back without the final k-step's contribution (rows 60..63 of the batch missing from every
+            // class 4g + 3: found by the oracle comparison at batch 64).  Eight more wait states, pinned in place.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MSTAMP(9);
+            upd_math(kind, c, dacc, pw);
+            w_write(c, pw);
+            MSTAMP(6);
+            wg_barrier();                                   // chunk's buffer free; after the last chunk: the whole W slice updated
+            MSTAMP(11);
         }
-        MSTAMP(6);
+        };
+        if (okind == UMLH_OPT_ADAMW) dw_phase(std::integral_constant<int, UMLH_OPT_ADAMW>{});
+        else if (okind == UMLH_OPT_ADAM) dw_phase(std::integral_constant<int, UMLH_OPT_ADAM>{});
+        else dw_phase(std::integral_constant<int, UMLH_OPT_SGD>{});
         // learnable logit scales (head.py:69-70): every slice applies the same update to its private copy
         if (learn) {
             auto upds = [&](auto kind) {
@@ -558,9 +570,11 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             else if (okind == UMLH_OPT_ADAM) upds(std::integral_constant<int, UMLH_OPT_ADAM>{});
             else upds(std::integral_constant<int, UMLH_OPT_SGD>{});
         }
-        // advance the offsets window to step k + 1 (the new last entry was loaded at the start of this step)
+        // advance: the next step's row pointers become current, the offsets window moves on
 #pragma unroll
-        for (int md = 0; md < 2; ++md) { off[md][0] = off[md][1]; off[md][1] = off[md][2]; off[md][2] = off_next[md]; }
+        for (int i = 0; i < DPW; ++i) rowp_cur[i] = rowp_nxt[i];
+#pragma unroll
+        for (int md = 0; md < 2; ++md) { off[md][0] = off[md][1]; off[md][1] = off[md][2]; off[md][2] = off[md][3]; off[md][3] = off_next[md]; }
     }
 
     if (stamping && tid == 0) {
@@ -569,7 +583,6 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
     }
 #undef MSTAMP
     // ---- write the resident state back ----
-    wait_vm<0>();
     wg_barrier();
     for (int i = tid; i < CS * (D / 4); i += 256) {
         const int r = i / (D / 4), q = i % (D / 4);

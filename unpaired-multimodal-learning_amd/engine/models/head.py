@@ -203,8 +203,18 @@ class _HeadBase(nn.Module):
     def zero_shot_init(self, zeroshot_dataset):
         print("=> Initializing head with zero-shot weights")
         dev = self.head.weight.device
-        w = get_zero_shot_weights(zeroshot_dataset, self.num_classes, self.shared_dim,
-                                  device=dev if dev.type == "cuda" else "cuda")
+        # a sweep initialises every grid point from the same text rows: the weights are computed once per dataset object
+        key = (id(zeroshot_dataset), self.num_classes, self.shared_dim)
+        cache = getattr(zeroshot_dataset, "_umlh_zero_shot", None)
+        if cache is not None and cache[0] == key:
+            w = cache[1]
+        else:
+            w = get_zero_shot_weights(zeroshot_dataset, self.num_classes, self.shared_dim,
+                                      device=dev if dev.type == "cuda" else "cuda")
+            try:
+                zeroshot_dataset._umlh_zero_shot = (key, w)
+            except AttributeError:
+                pass
         # in-place: keeps engine bindings valid (the reference rebinds .data, head.py:98)
         self.head.weight.data.copy_(w.to(dev))
 

@@ -367,9 +367,12 @@ def _eval_finish(stats_cpu, bs):
     """(val_loss, val_acc) from per-row stats: mean over batches of the per-batch mean CE, global mean of correct."""
     st = stats_cpu.double().numpy()
     n = st.shape[0]
-    starts = list(range(0, n, bs))
-    val_loss = float(sum(st[s0:s0 + bs, 0].sum() / min(bs, n - s0) for s0 in starts) / len(starts))
-    return val_loss, float(st[:, 1].sum() / n)
+    nb = (n + bs - 1) // bs
+    import numpy as np
+    sums = np.add.reduceat(st[:, 0], np.arange(0, n, bs))           # per-batch CE sums, in row order
+    counts = np.full(nb, bs, dtype=np.float64)
+    counts[-1] = n - (nb - 1) * bs
+    return float((sums / counts).sum() / nb), float(st[:, 1].sum() / n)
 
 
 def validate_many(pairs, extra=None):
@@ -548,7 +551,8 @@ def setup(datasets, hparams, args):
                             classifier_init=args.classifier_init, use_clip=args.use_clip, clip_logit=args.logit,
                             text_indim=getattr(args, "text_indim", None) if args.modality == "crossmodal"
                             else getattr(args, "common_dim", 0), device=args.device,
-                            eval_test=getattr(args, "eval_test", True), precision=getattr(args, "precision", "fp32"))
+                            eval_test=getattr(args, "eval_test", True), precision=getattr(args, "precision", "fp32"),
+                            tables=datasets.get("tables"))
     test_dict = {"test_acc": res["test_acc"], "val_acc": res["val_acc"], "model": res["model"], "iter": res["iter"]}
     print(f"=> Test Acc: {res['test_acc']:.4f}")
     torch.save(test_dict, test_path)
@@ -580,6 +584,10 @@ def sweep(datasets, hyperparams, args):
     if int(getattr(args, "sweep_workers", 1) or 1) > 1:
         return sweep_farm(datasets, hyperparams, args, int(args.sweep_workers))
     results = {"test_acc": [], "val_acc": [], "hparams": [], "model_records": []}
+    # the four feature tables are uploaded once for the whole sweep (every grid point reads the same rows)
+    if "tables" not in datasets and isinstance(datasets.get("img_tr"), (tuple, list)):
+        datasets = dict(datasets, tables=feature_tables(datasets["img_tr"], datasets["img_val"], datasets["img_te"],
+                                                        datasets["text_ds"], torch.device(getattr(args, "device", "cuda:0"))))
     for idx, hp in enumerate(_grid(hyperparams)):
         print(f"=> Running {idx + 1}: {hp}")
         out = setup(datasets, hp, args)
