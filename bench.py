@@ -125,6 +125,8 @@ def main():
             if rccl_ranks != args.gpus:
                 raise SystemExit(f"RCCL world size {rccl_ranks} != --gpus {args.gpus}")
 
+    if args.force_dp_path and not args.dp_host_loop:
+        os.environ["UMLH_FORCE_DP"] = "1"               # read at umlh_create: a lone rank takes the C-level split path
     import umlh
     from engine.datasets.utils import FeatureLoader, FeatureTable
     from engine.models.head import UMLClip
@@ -168,7 +170,8 @@ def main():
         stepper.broadcast_parameters([model.head.weight.data])
         tab_i, tab_t = img_src.table(precision), txt_src.table(precision)
         engine.bind_tables(tab_i, tab_t)
-        c_level_dp = world > 1 and not rehearsal and not args.dp_host_loop and stepper.attach_rccl()
+        c_level_dp = (world > 1 and not rehearsal and not args.dp_host_loop and stepper.attach_rccl()) or \
+                     (world == 1 and args.force_dp_path and not args.dp_host_loop)
 
         def slot(m):
             if cursor["k"] + m > ring:

@@ -114,9 +114,9 @@ typedef struct {
  * of the UNWEIGHTED per-modality head gradients g_img = dL_img/dW, g_txt = dL_txt/dW -- by-products
  * of the split-K slab reduction (image and text rows occupy separate slabs).  Written by
  * umlh_train_step(s) after umlh_enable_diagnostics(h, 1) (off by default: the accumulation costs
- * about 2.5 us per step at C*d = 512 000) when d_shared % 8 == 0; left untouched by umlh_eval_batch, zero in the
- * data-parallel split (umlh_grad_step / umlh_apply_update: per-modality gradients would need a
- * second all-reduce) and for a modality whose loss weight is 0.  The caller forms
+ * about 2.5 us per step at C*d = 512 000) when d_shared % 8 == 0; left untouched by umlh_eval_batch; in the
+ * data-parallel split they are written by umlh_apply_update from the all-reduced per-modality gradients (the message
+ * then carries g_img and g_txt separately); zero for a modality whose loss weight is 0.  The caller forms
  *   grad_direction_sim = DOT / sqrt(N2_IMG * N2_TXT),  img_grad_norm = sqrt(N2_IMG),
  *   txt_grad_norm = sqrt(N2_TXT),  grad_agreement_rate = AGREE / (C * d). */
 #define UMLH_S_GRAD_DOT      8   /* sum g_img * g_txt                          */
@@ -211,7 +211,29 @@ int  umlh_micro_launches(umlh_handle_t h, int64_t* out);
 /* Data-parallel split of the step: gradients only, laid out as ONE flat fp32
  * buffer [g_head | g_proj | g_scales(2) | scalars(UMLH_N_SCALARS)] inside the
  * workspace, already divided by batch->global_rows so a SUM all-reduce over ranks
- * yields the single-GPU gradient; then the update from that buffer. */
+ * yields the single-GPU gradient; then the update from that buffer.  With the gradient diagnostics enabled
+ * (d_shared % 8 == 0) the head part is [g_img | g_txt]: the two per-modality gradients travel separately and
+ * umlh_apply_update forms dot / norms / sign agreement from the all-reduced pair (pass the step's alpha / img_alpha in
+ * its hyper), so the diagnostics of a data-parallel step are those of the global batch. */
+/* Data-parallel transport.  With more than one rank attached, umlh_train_steps runs every step as
+ *   gradients -> SUM all-reduce -> identical update,
+ * all enqueued from C on the caller's stream (no host work per step): equal shards are assumed (every rank passes the same
+ * row counts per step; the CE means divide by rows x n_ranks).  For a 2-layer head the head gradient's all-reduce runs on
+ * a second stream beside the img_proj backward GEMMs.  The reference is single-process; there is no
+ * reference call site.
+ *   umlh_comm_unique_id / umlh_comm_init_rank: an RCCL communicator owned by the handle (librccl.so.1 is loaded at run
+ *     time; rank 0 draws the 128-byte id and hands it to the others, e.g. by a torch.distributed broadcast);
+ *   umlh_set_comm: attach an existing ncclComm_t instead;
+ *   umlh_set_allreduce: a custom transport -- fn(ctx, device_buf, n_floats, stream) must SUM-all-reduce the buffer in
+ *     place and be ordered with `stream` (tests plug gloo through a host callback; n_ranks == 1 makes umlh_train_steps take
+ *     the split path alone, for pricing). */
+#define UMLH_COMM_ID_BYTES 128
+typedef int (*umlh_allreduce_fn)(void* ctx, float* device_buf, uint64_t n_floats, void* stream);
+int  umlh_comm_unique_id(void* id_out /* UMLH_COMM_ID_BYTES */);
+int  umlh_comm_init_rank(umlh_handle_t h, const void* id, int32_t n_ranks, int32_t rank);
+int  umlh_set_comm(umlh_handle_t h, void* nccl_comm, int32_t n_ranks);
+int  umlh_set_allreduce(umlh_handle_t h, umlh_allreduce_fn fn, void* ctx, int32_t n_ranks);
+
 int  umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
                     const umlh_hyper_t* hyper, void* stream);
 int  umlh_grad_buffer(umlh_handle_t h, float** device_ptr, uint64_t* n_floats);

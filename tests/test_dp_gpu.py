@@ -182,3 +182,114 @@ def test_unequal_shards_rank_without_image_rows_applies_the_same_update():
     g2 = r2.grad_step(umlh.RowBatch(T(xi, torch.float32), T(yi, torch.int64), rows=0, global_rows=Bi),
                       umlh.RowBatch(T(xt, torch.float32), T(yt, torch.int64), rows=0, global_rows=Bt))
     assert float(g2.abs().max()) == 0.0
+
+
+def _worker_c_loop(rank, world, port, q, precision, proj):
+    """C-level data-parallel loop: umlh_train_steps with a transport attached runs grad -> all-reduce -> update per step
+    from C; the transport here is gloo through the all-reduce callback (RCCL refuses two ranks on one GPU)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "unpaired-multimodal-learning_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import umlh
+        rng = np.random.default_rng(8)
+        dv, dt, C, n, B, steps = 128, (256 if proj else 128), 50, 512, 64, 4
+        xi = rng.standard_normal((n, dv)).astype(np.float32); xi /= np.linalg.norm(xi, axis=1, keepdims=True)
+        xt = rng.standard_normal((n, dt)).astype(np.float32); xt /= np.linalg.norm(xt, axis=1, keepdims=True)
+        yi, yt = rng.integers(0, C, n), rng.integers(0, C, n)
+        wh = (rng.standard_normal((C, dt)) * 0.1).astype(np.float32)
+        wp = (rng.standard_normal((dt, dv)) / np.sqrt(dv)).astype(np.float32)
+        dev = "cuda:0"
+        e = umlh.HeadEngine(dv, dt, C, has_proj=proj, optimizer="sgd", weight_decay=0.0, max_rows_img=B, max_rows_txt=B,
+                            precision=precision, device=dev)
+        e.w_head.copy_(torch.from_numpy(wh)); e.scales.fill_(10.0)
+        if proj:
+            e.w_proj.copy_(torch.from_numpy(wp))
+        e.enable_diagnostics(True)
+        Xi, Yi, Xt, Yt = (torch.from_numpy(a).to(dev) for a in (xi, yi, xt, yt))
+        ti = (Xi, Yi, umlh.to_bf16(Xi)) if precision == "bf16" else (Xi, Yi)
+        tt = (Xt, Yt, umlh.to_bf16(Xt)) if precision == "bf16" else (Xt, Yt)
+        # global batch k = rows k*B .. k*B + B of a fixed order; rank r takes every world-th row of it
+        bi = [torch.arange(k * B + rank, (k + 1) * B, world, device=dev) for k in range(steps)]
+        bt = [torch.arange(k * B + rank, (k + 1) * B, world, device=dev) for k in range(steps)]
+        if world > 1:
+            e.set_allreduce(lambda t: dist.all_reduce(t), world)
+        sc = torch.zeros(steps, umlh.N_SCALARS, device=dev)
+        e.train_steps(ti, bi, tt, bt, [0.05] * steps, first_step=1, alpha=0.5, scalars_out=sc)
+        torch.cuda.synchronize()
+        q.put((rank, e.w_head.cpu().numpy(), e.w_proj.cpu().numpy() if proj else None, sc.cpu().numpy()))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision,proj", [("fp32", False), ("fp32", True), ("bf16", True)])
+def test_c_level_dp_loop_two_ranks_vs_single(precision, proj):
+    """umlh_train_steps with two ranks (transport through the all-reduce callback, the 2-layer head's head-gradient
+    all-reduce on the second stream) == the single-GPU fused steps on the concatenated batches: weights, step scalars and
+    the per-modality gradient diagnostics (formed from the all-reduced pair)."""
+    import torch.multiprocessing as mp
+    res = {}
+    for world in (1, 2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker_c_loop, args=(r, world, port, q, precision, proj)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        res[world] = sorted(out, key=lambda t: t[0])
+    _, w1, p1, s1 = res[1][0]
+    tol = 2e-6 if precision == "fp32" else 4e-3
+    for rank, w, pj, sc in res[2]:
+        np.testing.assert_allclose(w, w1, atol=tol * max(1.0, np.abs(w1).max()), rtol=0)
+        if proj:
+            np.testing.assert_allclose(pj, p1, atol=tol * max(1.0, np.abs(p1).max()), rtol=0)
+        np.testing.assert_allclose(sc[:, :4], s1[:, :4], atol=1e-5 if precision == "fp32" else 2e-3)
+        d2, d1 = sc[:, 8:12], s1[:, 8:12]                      # dot, |g_img|^2, |g_txt|^2, sign agreements
+        np.testing.assert_allclose(d2[:, :3], d1[:, :3], rtol=2e-3 if precision == "fp32" else 5e-2, atol=1e-9)
+        assert np.abs(d2[:, 3] - d1[:, 3]).max() <= (0.002 if precision == "fp32" else 0.05) * w1.size
+        assert d1[:, 1].min() > 0 and d1[:, 2].min() > 0
+    np.testing.assert_array_equal(res[2][0][1], res[2][1][1])
+
+
+def test_rccl_communicator_single_rank_round_trip(monkeypatch):
+    """librccl is loaded at run time and an RCCL communicator of ONE rank drives the C-level data-parallel loop
+    (UMLH_FORCE_DP=1 makes a lone rank take the split path): ncclAllReduce over one rank is the identity, so the result
+    equals the fused steps -- checks the loader, ncclCommInitRank, the enqueue order on the step's stream."""
+    import ctypes as C
+    import umlh
+    from umlh import _lib
+    rng = np.random.default_rng(4)
+    d, Cc, n, B, steps = 128, 40, 300, 96, 3
+    x = rng.standard_normal((n, d)).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = rng.integers(0, Cc, n)
+    w = (rng.standard_normal((Cc, d)) * 0.1).astype(np.float32)
+    dev = "cuda:0"
+    X, Y = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    bi = [torch.randperm(n, generator=torch.Generator().manual_seed(k))[:B].to(dev) for k in range(steps)]
+    out = []
+    for use_comm in (False, True):
+        if use_comm:
+            monkeypatch.setenv("UMLH_FORCE_DP", "1")          # read at umlh_create
+        e = umlh.HeadEngine(d, d, Cc, optimizer="adamw", weight_decay=0.01, max_rows_img=B, max_rows_txt=B, device=dev)
+        e.w_head.copy_(torch.from_numpy(w)); e.scales.fill_(10.0)
+        if use_comm:
+            idb = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+            _lib.check(e.lib.umlh_comm_unique_id(idb), "umlh_comm_unique_id")
+            _lib.check(e.lib.umlh_comm_init_rank(e.handle, idb, 1, 0), "umlh_comm_init_rank")
+        sc = torch.zeros(steps, umlh.N_SCALARS, device=dev)
+        e.train_steps((X, Y), bi, (X, Y), bi, [1e-3] * steps, first_step=1, scalars_out=sc)
+        torch.cuda.synchronize()
+        assert e.micro_launches() == 0
+        out.append((e.w_head.cpu().numpy(), sc.cpu().numpy()))
+        e.close()
+    diff = np.abs(out[1][0] - out[0][0])
+    assert (diff > 2e-6).mean() < 1e-3 and diff.max() < 5e-3          # Adam sign flips at |g| ~ eps aside
+    np.testing.assert_allclose(out[1][1][:, :4], out[0][1][:, :4], atol=1e-5)

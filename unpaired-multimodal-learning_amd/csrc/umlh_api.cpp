@@ -143,7 +143,8 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     L.slabs_head = take((long long)L.scap_head * L.n_head);
     L.slabs_proj = take((long long)L.scap_proj * L.n_proj);
     L.partials = take((long long)L.max_blocks * 4);
-    L.grads = take(L.n_head + L.n_proj + 2 + UMLH_N_SCALARS);
+    L.grads = take(2 * L.n_head + L.n_proj + 2 + UMLH_N_SCALARS);    // 2 x n_head: the data-parallel message carries the image and
+                                                                     // the text gradient separately when diagnostics are on
     L.w16 = take(c.precision == UMLH_PREC_BF16 ? 1024LL * c.d_shared / 2 : 0);   // bf16 chunk-major shadow of w_head (<= 1024 class rows)
     L.n_iota = L.rcap_img > L.rcap_txt ? L.rcap_img : L.rcap_txt;     // identity row ids: batch rows, classes, image-feature columns
     if (L.n_iota < 1024) L.n_iota = 1024;
@@ -195,6 +196,19 @@ struct umlh_handle_s {
     int stage_next;
     int micro_off;              // UMLH_MICRO=0: never take the micro path
     long long micro_launches;   // persistent launches this handle took part in (tests assert the path that ran)
+    // data-parallel stepping
+    bool dp_diag;               // layout of the gradient message: [g_img | g_txt | g_proj | g_scales | scalars] instead of [g_head | ...]
+    int n_ranks;                // > 1 (or dp_force): umlh_train_steps runs grad -> all-reduce -> update per step
+    int dp_force;               // UMLH_FORCE_DP=1 / umlh_set_allreduce with one rank: take the split path also alone (pricing, tests)
+    umlh_allreduce_fn ar_fn;    // custom transport (tests: gloo through a host callback), else RCCL through `comm`
+    void* ar_ctx;
+    void* comm;                 // ncclComm_t
+    bool comm_owned;
+    hipStream_t comm_stream;    // second stream: the head-gradient all-reduce of a 2-layer head runs beside the img_proj backward GEMMs
+    hipEvent_t ev_head_ready, ev_head_done;
+    bool overlap_pending;       // forward_backward calls dp_after_head() behind the dW_head GEMM
+    const umlh_hyper_t* overlap_hy;
+    const umlh_batch_t* overlap_img; const umlh_batch_t* overlap_txt;
     int device;                 // HIP device the handle was created on: every launching entry point runs there
     int global_rows_img, global_rows_txt;   // global row counts of the last umlh_grad_step (gate the update on every rank alike)
 };
@@ -209,6 +223,11 @@ struct DeviceGuard {
     }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+static void dp_release(umlh_handle_t h);
+static int grad_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy, hipStream_t st,
+                          bool comm);
+static int apply_update_impl(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_out, hipStream_t st);
 
 static inline void mark(umlh_handle_t h, int i, hipStream_t st) {
     if (h->profiling) (void)hipEventRecord(h->ev[i], st);
@@ -262,6 +281,9 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->profiling = false;
     h->micro_epoch = 0;
     h->micro_launches = 0;
+    h->dp_diag = false; h->n_ranks = 1; h->ar_fn = nullptr; h->ar_ctx = nullptr; h->comm = nullptr; h->comm_owned = false;
+    h->comm_stream = nullptr; h->overlap_pending = false;
+    { const char* e = getenv("UMLH_FORCE_DP"); h->dp_force = (e && atoi(e) == 1) ? 1 : 0; }
     h->stage = nullptr; h->stage_bytes = 0; h->stage_next = 0;
     { const char* e = getenv("UMLH_MICRO"); h->micro_off = (e && atoi(e) == 0) ? 1 : 0; }
     h->device = 0;
@@ -298,6 +320,15 @@ int umlh_profile_read(umlh_handle_t h, float* ms_out) {
 
 int umlh_destroy(umlh_handle_t h) {
     if (h && h->profiling) umlh_profile_enable(h, 0);
+    if (h) {
+        DeviceGuard dg_(h->device);
+        dp_release(h);
+        if (h->comm_stream) {
+            (void)hipStreamSynchronize(h->comm_stream);
+            (void)hipEventDestroy(h->ev_head_ready); (void)hipEventDestroy(h->ev_head_done);
+            (void)hipStreamDestroy(h->comm_stream);
+        }
+    }
     if (h && h->stage) {
         DeviceGuard dg_(h->device);
         (void)hipEventSynchronize(h->stage_ev[0]); (void)hipEventSynchronize(h->stage_ev[1]);
@@ -309,6 +340,11 @@ int umlh_destroy(umlh_handle_t h) {
 }
 
 static inline float* ws(umlh_handle_t h, long long off) { return static_cast<float*>(h->buf.workspace) + off; }
+
+// gradient message layout (see umlh_grad_step): head part, img_proj part, then g_scales(2) + scalars
+static inline long long msg_head_len(const umlh_handle_s* h) { return h->dp_diag ? 2 * h->L.n_head : h->L.n_head; }
+static inline long long msg_tail_off(const umlh_handle_s* h) { return msg_head_len(h) + h->L.n_proj; }
+static inline long long msg_len(const umlh_handle_s* h) { return msg_tail_off(h) + 2 + UMLH_N_SCALARS; }
 
 int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
     if (!h || !b) return fail(UMLH_E_INVALID, "umlh_bind: null argument");
@@ -614,6 +650,8 @@ int umlh_attention_backward(const float* qkv, const int64_t* lengths, const floa
     return UMLH_OK;
 }
 
+static int dp_after_head(umlh_handle_t h, int n_slabs_head, hipStream_t st);
+
 // Everything of a step up to (not including) the parameter update.
 static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt,
                             const umlh_hyper_t* hy, bool want_grad, hipStream_t st, int* n_slabs_head,
@@ -730,6 +768,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             *n_slabs_head = splits;
         }
         mark(h, 3, st);
+        if (h->overlap_pending) { int rc2 = dp_after_head(h, *n_slabs_head, st); if (rc2) return rc2; }
         if (proj) {
             // dH^T[n][r] = sum_c W_head[c][n] dZ^T[c][r]  (image columns), bf16 chunk-major out
             u16* wht16 = reinterpret_cast<u16*>(ws(h, L.wht16));
@@ -816,6 +855,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         *n_slabs_head = splits;
     }
     mark(h, 3, st);
+    if (h->overlap_pending) { int rc2 = dp_after_head(h, *n_slabs_head, st); if (rc2) return rc2; }
     *n_slabs_proj = 0;
     if (c.has_proj && ri > 0) {
         // dH^T[n][r] = sum_c W_head[c][n] dZ^T[c][r]   (image columns only)
@@ -861,7 +901,7 @@ static FinalizeArgs make_finalize(umlh_handle_t h, const umlh_batch_t* img, cons
     f.inv_rows1 = (txt && txt->rows > 0) ? 1.f / (float)txt->global_rows : 0.f;
     f.w0 = hy ? hy->img_alpha : 1.f;
     f.w1 = hy ? hy->alpha : 1.f;
-    f.tail = ws(h, h->L.grads) + h->L.n_head + h->L.n_proj;
+    f.tail = ws(h, h->L.grads) + msg_tail_off(h);
     f.scalars_out = scalars_out;
     f.scales = h->buf.scales; f.m_scales = h->buf.m_scales; f.v_scales = h->buf.v_scales;
     f.update_mask = 0;
@@ -895,7 +935,8 @@ static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_
     int sh = 0, sp = 0;
     // gradient diagnostics: accumulators in the caller's scalar row (or the workspace tail), zeroed by the
     // forward kernel, added to by the head-step blocks
-    float* tail = ws(h, h->L.grads) + h->L.n_head + h->L.n_proj;
+    h->dp_diag = false;
+    float* tail = ws(h, h->L.grads) + msg_tail_off(h);
     h->diag_dst = h->diagnostics ? (scalars_out ? scalars_out : tail + 2) + UMLH_N_CORE_SCALARS : nullptr;
     int rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
     if (rc) return rc;
@@ -1151,7 +1192,10 @@ int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_strea
     if ((img && (!img->offsets || !img->index)) || (txt && (!txt->offsets || !txt->index)))
         return fail(UMLH_E_INVALID, "umlh_train_steps: index/offsets required");
     DeviceGuard dg_(h->device);
-    if (micro_eligible(h, img, txt, n_steps)) {       // batch <= 64 linear head: one persistent launch for all n_steps
+    const bool dp = h->n_ranks > 1 || h->dp_force;
+    if (dp && h->n_ranks > 1 && !h->comm && !h->ar_fn)
+        return fail(UMLH_E_UNBOUND, "umlh_train_steps: %d ranks but no communicator", h->n_ranks);
+    if (!dp && micro_eligible(h, img, txt, n_steps)) {       // batch <= 64 linear head: one persistent launch for all n_steps
         MicroItem it{h, img, txt, lr, first_step, alpha, img_alpha, scalars_out};
         return micro_run(&it, 1, n_steps, (hipStream_t)stream);
     }
@@ -1174,12 +1218,221 @@ int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_strea
         int rc = check_step(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy, "umlh_train_steps");
         if (rc) return rc;
         if (k == 0) h->shadow_fresh = false;
-        rc = train_step_impl(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy,
-                             scalars_out ? scalars_out + (size_t)k * UMLH_N_SCALARS : nullptr, (hipStream_t)stream,
-                             k + 1 < n_steps);
+        float* so = scalars_out ? scalars_out + (size_t)k * UMLH_N_SCALARS : nullptr;
+        if (dp) {
+            // data parallel, equal shards: every rank brings the same row counts, the CE means divide by rows x ranks;
+            // gradients -> SUM all-reduce (RCCL, enqueued on the same stream) -> identical update on every rank
+            bi.global_rows = bi.rows * h->n_ranks;
+            bt.global_rows = bt.rows * h->n_ranks;
+            if (k > 0) hy.flags |= UMLH_F_WEIGHTS_UNCHANGED;      // the shadow of the weights this loop wrote is current
+            rc = grad_step_impl(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy, (hipStream_t)stream, true);
+            if (!rc) rc = apply_update_impl(h, &hy, so, (hipStream_t)stream);
+        } else {
+            rc = train_step_impl(h, img ? &bi : nullptr, txt ? &bt : nullptr, &hy, so, (hipStream_t)stream, k + 1 < n_steps);
+        }
         if (rc) return rc;
     }
     h->shadow_fresh = false;
+    return UMLH_OK;
+}
+
+// ---- RCCL, loaded at run time (the library has no link-time dependency on it; a process that imported torch already
+// holds librccl.so.1 and gets that copy) ----
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+static RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return;
+        api.get_unique_id = reinterpret_cast<decltype(api.get_unique_id)>(dlsym(lib, "ncclGetUniqueId"));
+        api.comm_init_rank = reinterpret_cast<decltype(api.comm_init_rank)>(dlsym(lib, "ncclCommInitRank"));
+        api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(dlsym(lib, "ncclAllReduce"));
+        api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+        api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(lib, "ncclGetErrorString"));
+        if (api.get_unique_id && api.comm_init_rank && api.all_reduce && api.comm_destroy) api.lib = lib;
+    });
+    return api.lib ? &api : nullptr;
+}
+
+int umlh_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(UMLH_E_INVALID, "umlh_comm_unique_id: null argument");
+    RcclApi* r = rccl_api();
+    if (!r) return fail(UMLH_E_HIP, "umlh_comm_unique_id: librccl.so.1 could not be loaded");
+    ncclUniqueId id;
+    ncclResult_t e = r->get_unique_id(&id);
+    if (e != ncclSuccess) return fail(UMLH_E_HIP, "ncclGetUniqueId: %s", r->error_string ? r->error_string(e) : "error");
+    memcpy(id_out, &id, UMLH_COMM_ID_BYTES);
+    return UMLH_OK;
+}
+
+static int dp_streams(umlh_handle_t h) {
+    if (h->comm_stream) return UMLH_OK;
+    HIPCHK((int)hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking), "data parallel: comm stream");
+    HIPCHK((int)hipEventCreateWithFlags(&h->ev_head_ready, hipEventDisableTiming), "data parallel: event");
+    HIPCHK((int)hipEventCreateWithFlags(&h->ev_head_done, hipEventDisableTiming), "data parallel: event");
+    return UMLH_OK;
+}
+
+static void dp_release(umlh_handle_t h) {
+    if (h->comm && h->comm_owned) { RcclApi* r = rccl_api(); if (r) (void)r->comm_destroy(static_cast<ncclComm_t>(h->comm)); }
+    h->comm = nullptr; h->comm_owned = false; h->ar_fn = nullptr; h->ar_ctx = nullptr; h->n_ranks = 1;
+}
+
+int umlh_comm_init_rank(umlh_handle_t h, const void* id, int32_t n_ranks, int32_t rank) {
+    if (!h || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(UMLH_E_INVALID, "umlh_comm_init_rank: bad arguments");
+    RcclApi* r = rccl_api();
+    if (!r) return fail(UMLH_E_HIP, "umlh_comm_init_rank: librccl.so.1 could not be loaded");
+    DeviceGuard dg_(h->device);
+    dp_release(h);
+    ncclUniqueId uid;
+    memcpy(&uid, id, UMLH_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    ncclResult_t e = r->comm_init_rank(&comm, n_ranks, uid, rank);
+    if (e != ncclSuccess) return fail(UMLH_E_HIP, "ncclCommInitRank: %s", r->error_string ? r->error_string(e) : "error");
+    h->comm = comm; h->comm_owned = true; h->n_ranks = n_ranks;
+    return dp_streams(h);
+}
+
+int umlh_set_comm(umlh_handle_t h, void* nccl_comm, int32_t n_ranks) {
+    if (!h || n_ranks < 1 || (!nccl_comm && n_ranks > 1)) return fail(UMLH_E_INVALID, "umlh_set_comm: bad arguments");
+    if (nccl_comm && !rccl_api()) return fail(UMLH_E_HIP, "umlh_set_comm: librccl.so.1 could not be loaded");
+    DeviceGuard dg_(h->device);
+    dp_release(h);
+    h->comm = nccl_comm; h->comm_owned = false; h->n_ranks = n_ranks;
+    return nccl_comm ? dp_streams(h) : UMLH_OK;
+}
+
+int umlh_set_allreduce(umlh_handle_t h, umlh_allreduce_fn fn, void* ctx, int32_t n_ranks) {
+    if (!h || n_ranks < 1 || (!fn && n_ranks > 1)) return fail(UMLH_E_INVALID, "umlh_set_allreduce: bad arguments");
+    DeviceGuard dg_(h->device);
+    dp_release(h);
+    h->ar_fn = fn; h->ar_ctx = ctx; h->n_ranks = n_ranks;
+    if (fn && n_ranks == 1) h->dp_force = 1;
+    return fn ? dp_streams(h) : UMLH_OK;
+}
+
+// SUM all-reduce of `n` floats in place, enqueued on `st`
+static int dp_allreduce(umlh_handle_t h, float* buf, long long n, hipStream_t st) {
+    if (n <= 0) return UMLH_OK;
+    if (h->ar_fn) {
+        int rc = h->ar_fn(h->ar_ctx, buf, (uint64_t)n, st);
+        return rc ? fail(UMLH_E_HIP, "data parallel: the all-reduce callback failed with code %d", rc) : UMLH_OK;
+    }
+    if (h->comm) {
+        RcclApi* r = rccl_api();
+        ncclResult_t e = r->all_reduce(buf, buf, (size_t)n, ncclFloat, ncclSum, static_cast<ncclComm_t>(h->comm), st);
+        if (e != ncclSuccess) return fail(UMLH_E_HIP, "ncclAllReduce: %s", r->error_string ? r->error_string(e) : "error");
+        return UMLH_OK;
+    }
+    return h->n_ranks > 1 ? fail(UMLH_E_UNBOUND, "data parallel: %d ranks but no communicator (umlh_comm_init_rank / umlh_set_comm / umlh_set_allreduce)", h->n_ranks)
+                          : UMLH_OK;
+}
+
+// Sum the dW_head slabs into the gradient message: [g_head], or [g_img | g_txt] when the per-modality gradient
+// diagnostics are on (finetune.py:190-191,203-206 need the GLOBAL per-modality gradients: dot products and norms are
+// not linear in the ranks' partial sums, so the two sums travel separately and the update kernel forms the diagnostics
+// from the all-reduced pair).
+static int dp_reduce_head(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy, int sh,
+                          hipStream_t st) {
+    OptArgs o = make_opt(h->cfg, *hy);
+    FinalizeArgs f = make_finalize(h, img, txt, hy, true, nullptr, false);
+    float* grads = ws(h, h->L.grads);
+    const long long nh = h->L.n_head;
+    if (h->dp_diag) {
+        const int si = h->n_slabs_img < sh ? h->n_slabs_img : sh;
+        FinalizeArgs f2 = f;
+        f2.partials = nullptr;                           // the step scalars are formed once (first launch)
+        DiagArgs none; none.dst = nullptr; none.n_slabs_img = si; none.inv_w0 = none.inv_w1 = 0.f;
+        if (si > 0) HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), si, nh, h->cfg.num_classes, h->cfg.d_shared, nullptr, nullptr,
+                                                 nullptr, &o, nullptr, 32 * h->ctw * h->wc, &f, grads, &none, st), "reduce head (image rows)");
+        else HIPCHK((int)hipMemsetAsync(grads, 0, sizeof(float) * nh, st), "zero image gradient");
+        none.n_slabs_img = 0;
+        if (sh - si > 0) HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head) + (size_t)si * nh, sh - si, nh, h->cfg.num_classes, h->cfg.d_shared,
+                                                      nullptr, nullptr, nullptr, &o, nullptr, 32 * h->ctw * h->wc, si > 0 ? &f2 : &f, grads + nh,
+                                                      &none, st), "reduce head (text rows)");
+        else HIPCHK((int)hipMemsetAsync(grads + nh, 0, sizeof(float) * nh, st), "zero text gradient");
+        return UMLH_OK;
+    }
+    if (h->cfg.d_shared % 8 == 0) {
+        HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, nh, h->cfg.num_classes, h->cfg.d_shared, nullptr, nullptr, nullptr, &o,
+                                     nullptr, 32 * h->ctw * h->wc, &f, grads, nullptr, st), "reduce head");
+    } else {
+        HIPCHK(umlh_launch_finalize(&f, st), "finalize");
+        HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, nh, nh, grads, nullptr, nullptr, nullptr, &o, st), "reduce head");
+    }
+    return UMLH_OK;
+}
+
+// 2-layer head, data parallel: the head gradient is complete behind the dW_head GEMM; its all-reduce (12.8 MB at cfg3)
+// runs on the second stream beside the img_proj backward GEMMs (dH^T, dW_proj) of the step's stream.
+static int dp_after_head(umlh_handle_t h, int n_slabs_head, hipStream_t st) {
+    h->overlap_pending = false;
+    int rc = dp_reduce_head(h, h->overlap_img, h->overlap_txt, h->overlap_hy, n_slabs_head, st);
+    if (rc) return rc;
+    HIPCHK((int)hipEventRecord(h->ev_head_ready, st), "data parallel: event record");
+    HIPCHK((int)hipStreamWaitEvent(h->comm_stream, h->ev_head_ready, 0), "data parallel: stream wait");
+    rc = dp_allreduce(h, ws(h, h->L.grads), msg_head_len(h), h->comm_stream);
+    if (rc) return rc;
+    HIPCHK((int)hipEventRecord(h->ev_head_done, h->comm_stream), "data parallel: event record");
+    return UMLH_OK;
+}
+
+// Gradients of one step into the message buffer.  `comm`: also all-reduce it (the data-parallel multi-step loop); the
+// head part then overlaps the img_proj backward when the head has one.
+static int grad_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy, hipStream_t st,
+                          bool comm) {
+    int sh = 0, sp = 0;
+    h->last_rows_img = img ? img->rows : 0;
+    h->last_rows_txt = txt ? txt->rows : 0;
+    h->global_rows_img = img ? img->global_rows : 0;
+    h->global_rows_txt = txt ? txt->global_rows : 0;
+    h->dp_diag = h->diagnostics && h->cfg.d_shared % 8 == 0;
+    float* grads = ws(h, h->L.grads);
+    if (h->last_rows_img + h->last_rows_txt == 0) {       // no local row: this rank contributes zeros to the all-reduce
+        HIPCHK((int)hipMemsetAsync(grads, 0, sizeof(float) * msg_len(h), st), "zero gradient buffer");
+        return comm ? dp_allreduce(h, grads, msg_len(h), st) : UMLH_OK;
+    }
+    if (!(hy->flags & UMLH_F_WEIGHTS_UNCHANGED)) h->shadow_fresh = false;
+    h->diag_dst = nullptr;                                // the diagnostics of a split step are formed by umlh_apply_update
+    const bool overlap = comm && h->cfg.has_proj && h->comm_stream != nullptr && (img ? img->rows : 0) > 0;
+    h->overlap_pending = overlap;
+    h->overlap_hy = hy; h->overlap_img = img; h->overlap_txt = txt;
+    int rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
+    h->overlap_pending = false;
+    if (rc) return rc;
+    if (!overlap) { rc = dp_reduce_head(h, img, txt, hy, sh, st); if (rc) return rc; }
+    OptArgs o = make_opt(h->cfg, *hy);
+    if (h->cfg.has_proj) {
+        float* gp = grads + msg_head_len(h);
+        if (sp > 0)
+            HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj, gp, nullptr, nullptr, nullptr, &o, st),
+                   "reduce proj");
+        else
+            HIPCHK((int)hipMemsetAsync(gp, 0, sizeof(float) * h->L.n_proj, st), "zero proj grad");
+    }
+    mark(h, 5, st);
+    if (comm) {
+        if (overlap) {                                    // head part is in flight on the second stream: the rest here, then join
+            rc = dp_allreduce(h, grads + msg_head_len(h), msg_len(h) - msg_head_len(h), st);
+            if (rc) return rc;
+            HIPCHK((int)hipStreamWaitEvent(st, h->ev_head_done, 0), "data parallel: stream wait");
+        } else {
+            rc = dp_allreduce(h, grads, msg_len(h), st);
+            if (rc) return rc;
+        }
+    }
     return UMLH_OK;
 }
 
@@ -1188,43 +1441,7 @@ int umlh_grad_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t*
     int rc = check_step(h, img, txt, hy, "umlh_grad_step", true);
     if (rc) return rc;
     DeviceGuard dg_(h->device);
-    hipStream_t st = (hipStream_t)stream;
-    int sh = 0, sp = 0;
-    h->last_rows_img = img ? img->rows : 0;
-    h->last_rows_txt = txt ? txt->rows : 0;
-    h->global_rows_img = img ? img->global_rows : 0;
-    h->global_rows_txt = txt ? txt->global_rows : 0;
-    if (h->last_rows_img + h->last_rows_txt == 0) {       // no local row: this rank contributes zeros to the all-reduce
-        HIPCHK((int)hipMemsetAsync(ws(h, h->L.grads), 0, sizeof(float) * (h->L.n_head + h->L.n_proj + 2 + UMLH_N_SCALARS), st),
-               "zero gradient buffer");
-        return UMLH_OK;
-    }
-    if (!(hy->flags & UMLH_F_WEIGHTS_UNCHANGED)) h->shadow_fresh = false;
-    // the diagnostic slots of the flat buffer are zeroed (per-modality gradients of a data-parallel step
-    // would need a second all-reduce; not produced)
-    h->diag_dst = ws(h, h->L.grads) + h->L.n_head + h->L.n_proj + 2 + UMLH_N_CORE_SCALARS;
-    rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
-    if (rc) return rc;
-    OptArgs o = make_opt(h->cfg, *hy);
-    FinalizeArgs f = make_finalize(h, img, txt, hy, true, nullptr, false);
-    float* grads = ws(h, h->L.grads);
-    if (h->cfg.d_shared % 8 == 0) {
-        HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, h->L.n_head, h->cfg.num_classes, h->cfg.d_shared, nullptr,
-                                     nullptr, nullptr, &o, nullptr, 32 * h->ctw * h->wc, &f, grads, nullptr, st), "reduce head");
-    } else {
-        HIPCHK(umlh_launch_finalize(&f, st), "finalize");
-        HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, grads, nullptr,
-                                         nullptr, nullptr, &o, st), "reduce head");
-    }
-    if (h->cfg.has_proj) {
-        if (sp > 0)
-            HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj,
-                                             grads + h->L.n_head, nullptr, nullptr, nullptr, &o, st), "reduce proj");
-        else
-            HIPCHK((int)hipMemsetAsync(grads + h->L.n_head, 0, sizeof(float) * h->L.n_proj, st), "zero proj grad");
-    }
-    mark(h, 5, st);
-    return UMLH_OK;
+    return grad_step_impl(h, img, txt, hy, (hipStream_t)stream, false);
 }
 
 int umlh_debug_buffer(umlh_handle_t h, void** device_ptr, uint64_t* n_bytes) {
@@ -1237,23 +1454,31 @@ int umlh_debug_buffer(umlh_handle_t h, void** device_ptr, uint64_t* n_bytes) {
 int umlh_grad_buffer(umlh_handle_t h, float** device_ptr, uint64_t* n_floats) {
     if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_grad_buffer: handle not bound");
     if (device_ptr) *device_ptr = ws(h, h->L.grads);
-    if (n_floats) *n_floats = (uint64_t)(h->L.n_head + h->L.n_proj + 2 + UMLH_N_SCALARS);
+    const bool diag = h->diagnostics && h->cfg.d_shared % 8 == 0;        // the layout umlh_grad_step will use
+    if (n_floats) *n_floats = (uint64_t)((diag ? 2 : 1) * h->L.n_head + h->L.n_proj + 2 + UMLH_N_SCALARS);
     return UMLH_OK;
 }
 
-int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_out, void* stream) {
-    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_apply_update: handle not bound");
-    if (!hy) return fail(UMLH_E_INVALID, "umlh_apply_update: hyper is null");
-    DeviceGuard dg_(h->device);
-    hipStream_t st = (hipStream_t)stream;
+static int apply_update_impl(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_out, hipStream_t st) {
     OptArgs o = make_opt(h->cfg, *hy);
     float* grads = ws(h, h->L.grads);
     FinalizeArgs f = make_finalize(h, nullptr, nullptr, hy, false, scalars_out, true);
     if (h->cfg.d_shared % 8 == 0) {
         const bool bf = h->cfg.precision == UMLH_PREC_BF16;
-        HIPCHK(umlh_launch_head_step(grads, 1, h->L.n_head, h->cfg.num_classes, h->cfg.d_shared, h->buf.w_head, h->buf.m_head,
-                                     h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr, 32 * h->ctw * h->wc, &f, nullptr,
-                                     nullptr, st), "update head");
+        DiagArgs dg;
+        dg.dst = nullptr; dg.n_slabs_img = 1; dg.inv_w0 = dg.inv_w1 = 0.f;
+        if (h->dp_diag) {
+            // the two all-reduced per-modality gradients are the two "slabs" of the update kernel: it sums them, steps the
+            // weights and accumulates dot / norms / sign agreement of the GLOBAL gradients (finetune.py:203-206)
+            float* dst = (scalars_out ? scalars_out : f.tail + 2) + UMLH_N_CORE_SCALARS;
+            HIPCHK((int)hipMemsetAsync(dst, 0, sizeof(float) * (UMLH_N_SCALARS - UMLH_N_CORE_SCALARS), st), "zero diagnostics");
+            dg.dst = dst;
+            dg.inv_w0 = hy->img_alpha != 0.f ? 1.f / hy->img_alpha : 0.f;
+            dg.inv_w1 = hy->alpha != 0.f ? 1.f / hy->alpha : 0.f;
+        }
+        HIPCHK(umlh_launch_head_step(grads, h->dp_diag ? 2 : 1, h->L.n_head, h->cfg.num_classes, h->cfg.d_shared, h->buf.w_head,
+                                     h->buf.m_head, h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr, 32 * h->ctw * h->wc, &f, nullptr,
+                                     h->dp_diag ? &dg : nullptr, st), "update head");
         h->shadow_fresh = bf;              // the next umlh_grad_step may trust it (see umlh_grad_step)
     } else {
         HIPCHK(umlh_launch_reduce_update(1, grads, 1, h->L.n_head, h->L.n_head, nullptr, h->buf.w_head, h->buf.m_head,
@@ -1261,9 +1486,16 @@ int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_ou
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
     }
     if (h->cfg.has_proj && h->global_rows_img > 0)
-        HIPCHK(umlh_launch_reduce_update(1, grads + h->L.n_head, 1, h->L.n_proj, h->L.n_proj, nullptr, h->buf.w_proj,
+        HIPCHK(umlh_launch_reduce_update(1, grads + msg_head_len(h), 1, h->L.n_proj, h->L.n_proj, nullptr, h->buf.w_proj,
                                          h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
     return UMLH_OK;
+}
+
+int umlh_apply_update(umlh_handle_t h, const umlh_hyper_t* hy, float* scalars_out, void* stream) {
+    if (!h || !h->bound) return fail(UMLH_E_UNBOUND, "umlh_apply_update: handle not bound");
+    if (!hy) return fail(UMLH_E_INVALID, "umlh_apply_update: hyper is null");
+    DeviceGuard dg_(h->device);
+    return apply_update_impl(h, hy, scalars_out, (hipStream_t)stream);
 }
 
 int umlh_eval_batch(umlh_handle_t h, const umlh_batch_t* b, float* scalars_out, void* stream) {

@@ -25,7 +25,8 @@ EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_w
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_eval_rows", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
-           "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_seq_mse_forward", "umlh_seq_mse_backward",
+           "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_comm_unique_id", "umlh_comm_init_rank",
+           "umlh_set_comm", "umlh_set_allreduce", "umlh_seq_mse_forward", "umlh_seq_mse_backward",
            "umlh_random_permutation", "umlh_debug_buffer",
            "umlh_gemm_f32", "umlh_add_inplace", "umlh_bias_act", "umlh_relu_backward", "umlh_dropout", "umlh_colsum",
            "umlh_add_layernorm_forward", "umlh_layernorm_backward", "umlh_add_positions", "umlh_positions_backward",
@@ -58,6 +59,10 @@ class Batch(C.Structure):
 class Stream(C.Structure):
     _fields_ = [("feats", C.c_void_p), ("feats_bf16", C.c_void_p), ("labels", C.c_void_p), ("index", C.c_void_p),
                 ("offsets", C.POINTER(C.c_int32))]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # umlh_allreduce_fn
+COMM_ID_BYTES = 128
 
 
 class GroupItem(C.Structure):
@@ -150,6 +155,10 @@ def load_library():
     lib.umlh_train_steps_grouped.argtypes = [C.POINTER(GroupItem), i32, i32, vp]
     lib.umlh_micro_status.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.umlh_micro_launches.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.umlh_comm_unique_id.argtypes = [vp]
+    lib.umlh_comm_init_rank.argtypes = [vp, vp, i32, i32]
+    lib.umlh_set_comm.argtypes = [vp, vp, i32]
+    lib.umlh_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32]
     lib.umlh_seq_mse_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.umlh_seq_mse_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.umlh_random_permutation.argtypes = [i64, u64, vp, vp]

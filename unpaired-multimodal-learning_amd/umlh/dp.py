@@ -65,7 +65,10 @@ class DataParallelStepper:
         except TypeError:              # engines without the hint (test doubles)
             flat = self.engine.grad_step(self._with_global(img), self._with_global(txt), alpha=alpha, img_alpha=img_alpha)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        out = self.engine.apply_update(lr=lr, step=step, scalars_out=scalars_out)
+        try:
+            out = self.engine.apply_update(lr=lr, step=step, scalars_out=scalars_out, alpha=alpha, img_alpha=img_alpha)
+        except TypeError:              # engines without the loss weights in apply_update (test doubles)
+            out = self.engine.apply_update(lr=lr, step=step, scalars_out=scalars_out)
         self._own_weights = True
         return out
 
@@ -75,11 +78,10 @@ class DataParallelStepper:
         two index vectors change.  Equal shards assumed unless the global row counts are given."""
         gi = global_img if global_img is not None else (idx_img.numel() * self.world if idx_img is not None else 0)
         gt = global_txt if global_txt is not None else (idx_txt.numel() * self.world if idx_txt is not None else 0)
-        if self._flat is None:
-            self._flat = self.engine.grad_buffer()
+        self._flat = self.engine.grad_buffer()          # its length follows the diagnostics switch
         self.engine.grad_step_indexed(idx_img, idx_txt, gi, gt, alpha, img_alpha, weights_unchanged=self._own_weights)
         if self.world > 1:
             dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-        out = self.engine.apply_update(lr=lr, step=step, scalars_out=scalars_out)
+        out = self.engine.apply_update(lr=lr, step=step, scalars_out=scalars_out, alpha=alpha, img_alpha=img_alpha)
         self._own_weights = True
         return out

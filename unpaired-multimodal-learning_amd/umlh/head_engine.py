@@ -296,14 +296,58 @@ class HeadEngine:
               "umlh_grad_step")
 
     def grad_buffer(self) -> torch.Tensor:
-        """Flat fp32 view [g_head | g_proj | g_scales(2) | scalars(8)] inside the workspace."""
+        """Flat fp32 view of the gradient message inside the workspace: [g_head | g_proj | g_scales(2) | scalars(12)], with the
+        head part [g_img | g_txt] while the gradient diagnostics are enabled."""
         p, n = C.c_void_p(), C.c_uint64()
         check(self.lib.umlh_grad_buffer(self.handle, C.byref(p), C.byref(n)), "umlh_grad_buffer")
         off = (p.value - self.workspace.data_ptr()) // 4
         return self.workspace[off:off + n.value]
 
-    def apply_update(self, lr: float, step: int, scalars_out: Optional[torch.Tensor] = None):
-        hy = Hyper(float(lr), int(step), 1.0, 1.0, 0, 0)
+    # -- data-parallel transport ---------------------------------------------------------------------
+    def init_rccl(self, group=None) -> bool:
+        """Give this engine an RCCL communicator of its own over the ranks of ``group`` (``umlh_comm_init_rank``): rank 0
+        draws the unique id, ``torch.distributed`` (whatever backend the group runs on) carries its 128 bytes to the
+        others.  Afterwards ``train_steps`` runs whole data-parallel steps from C: gradients -> ncclAllReduce -> update on
+        the step's stream.  Returns False if librccl could not be loaded."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        idb = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        ok = 1
+        if rank == 0:
+            ok = 1 if self.lib.umlh_comm_unique_id(idb) == 0 else 0
+        dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([ok] + list(idb), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        vals = t.cpu().tolist()
+        if not vals[0]:
+            return False
+        idb = (C.c_ubyte * _lib.COMM_ID_BYTES)(*vals[1:])
+        check(self.lib.umlh_comm_init_rank(self.handle, idb, world, rank), "umlh_comm_init_rank")
+        return True
+
+    def set_allreduce(self, fn, n_ranks: int) -> None:
+        """Custom transport for the C-level data-parallel loop (``umlh_set_allreduce``): ``fn(tensor)`` must SUM-all-reduce
+        the given fp32 view of the gradient message in place, ordered with the current stream (tests: gloo).  ``fn=None``
+        detaches."""
+        if fn is None:
+            self._ar_cb = None
+            check(self.lib.umlh_set_allreduce(self.handle, _lib.ALLREDUCE_FN(), None, 1), "umlh_set_allreduce")
+            return
+
+        def cb(ctx, buf, n, stream):
+            try:
+                off = (int(buf) - self.workspace.data_ptr()) // 4
+                fn(self.workspace[off:off + int(n)])
+                return 0
+            except Exception as exc:            # noqa: BLE001 -- the C side turns the code into an UmlhError
+                print(f"umlh all-reduce callback failed: {exc!r}")
+                return 1
+        self._ar_cb = _lib.ALLREDUCE_FN(cb)     # keep the thunk alive as long as the engine
+        check(self.lib.umlh_set_allreduce(self.handle, self._ar_cb, None, int(n_ranks)), "umlh_set_allreduce")
+
+    def apply_update(self, lr: float, step: int, scalars_out: Optional[torch.Tensor] = None, alpha: float = 1.0,
+                     img_alpha: float = 1.0):
+        hy = Hyper(float(lr), int(step), float(alpha), float(img_alpha), 0, 0)
         so = scalars_out if scalars_out is not None else self._scalars
         check(self.lib.umlh_apply_update(self.handle, C.byref(hy), _ptr(so), self._stream()), "umlh_apply_update")
         return so
