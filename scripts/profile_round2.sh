@@ -1,0 +1,30 @@
+#!/bin/bash
+# usage (on the GPU box): scripts/profile_round2.sh <tag>   e.g. r02  -- everything the round's profiles/ files come from
+set -e
+tag=$1
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $root
+o=gpurun_out
+python bench.py > $o/${tag}_bench.log 2>&1 || { tail -5 $o/${tag}_bench.log; exit 1; }
+tail -1 $o/${tag}_bench.log > $o/${tag}_bench.json
+python bench.py --gpus 1 --steps 20 --warmup 5 > $o/${tag}_bench_driver_args.log 2>&1; tail -1 $o/${tag}_bench_driver_args.log > $o/${tag}_bench_driver_args.json
+python bench.py --force-dp-path --no-cpu-baseline --no-fp32-leg > $o/${tag}_force_dp.log 2>&1; tail -1 $o/${tag}_force_dp.log > $o/${tag}_bench_force_dp_c_loop.json
+python bench.py --force-dp-path --dp-host-loop --no-cpu-baseline --no-fp32-leg > $o/${tag}_force_dp_host.log 2>&1; tail -1 $o/${tag}_force_dp_host.log > $o/${tag}_bench_force_dp_host_loop.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/${tag}_kt -o kt -- python3 $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $root/$o/${tag}_kt.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/$o/${tag}_pmc_f -o pmc -- python3 $root/bench.py --steps 20 --warmup 3 --repeats 3 --prime 20 --no-cpu-baseline --no-fp32-leg > $root/$o/${tag}_pmc_f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/$o/${tag}_pmc_w -o pmc -- python3 $root/bench.py --steps 20 --warmup 3 --repeats 3 --prime 20 --no-cpu-baseline --no-fp32-leg > $root/$o/${tag}_pmc_w.log 2>&1
+cd $root
+python scripts/summarize_rocprof.py $(dirname $(find $o/${tag}_kt -name "kt_kernel_stats.csv" | head -1)) kt $o/${tag}_kernel_stats.md "Command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline (bf16 headline + fp32 parity leg; cfg2; MI355X; scripts/profile_round2.sh)" > /dev/null
+python scripts/make_pmc_json.py $(find $o/${tag}_pmc_f -name "*counter_collection.csv" | head -1) $(find $o/${tag}_pmc_w -name "*counter_collection.csv" | head -1) $o/${tag}_bf16_pmc.json > /dev/null
+# micro step: per-phase stamps, step time, sweeps
+python scripts/micro_stamps.py 512 100 32 4096 > $o/${tag}_micro_stamps.txt 2>&1
+python scripts/small_step_timing.py 32 fp32 4 > $o/${tag}_micro_step_timing.txt 2>&1
+UMLH_MICRO=0 python scripts/small_step_timing.py 32 fp32 4 >> $o/${tag}_micro_step_timing.txt 2>&1
+python scripts/bench_farm.py --iters 1000 --workers 1 --grouped > $o/${tag}_farm.txt 2>&1
+python scripts/bench_farm.py --iters 4000 --workers 1 --grouped >> $o/${tag}_farm.txt 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/${tag}_kt_micro -o kt -- python3 $root/scripts/small_step_timing.py 32 fp32 4 > $root/$o/${tag}_kt_micro.log 2>&1
+cd $root
+python scripts/summarize_rocprof.py $(dirname $(find $o/${tag}_kt_micro -name "kt_kernel_stats.csv" | head -1)) kt $o/${tag}_micro_kernel_stats.md "Command: rocprofv3 --kernel-trace --stats -- python3 scripts/small_step_timing.py 32 fp32 4 (cfg1 shape d=512 C=100, batch 32+32, 4 x 100 steps through umlh_train_steps = 4 persistent launches of 100 steps each)" > /dev/null
+tail -2 $o/${tag}_bench.json | cut -c1-600

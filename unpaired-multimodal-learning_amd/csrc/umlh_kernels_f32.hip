@@ -602,38 +602,39 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
 }
 
+// 4 consecutive elements per thread (twice the workgroups of an 8-element split: at C*d = 512 000 that is 500 workgroups
+// = 2 per CU instead of one 4-wave workgroup per CU, and the kernel is bound by bytes in flight, not by arithmetic).
 __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                         int C, int K, float* __restrict__ p, float* __restrict__ m,
                                                         float* __restrict__ v, OptArgs o, unsigned short* __restrict__ shadow,
                                                         int cpad, FinalizeArgs f, float* __restrict__ grad_out, DiagArgs dg) {
     __shared__ float sh[6][256];
     if (blockIdx.x == gridDim.x - 1) { finalize_body(f, sh); return; }
-    const long long g8 = (long long)blockIdx.x * 256 + threadIdx.x;      // group of 8 consecutive k of one class row
-    const long long n8 = (long long)C * K / 8;
-    const bool live = g8 < n8;
-    const long long i = (live ? g8 : 0) * 8;
+    const long long g4 = (long long)blockIdx.x * 256 + threadIdx.x;      // group of 4 consecutive k of one class row
+    const long long n4 = (long long)C * K / 4;
+    const bool live = g4 < n4;
+    const long long i = (live ? g4 : 0) * 4;
     // image slabs and text slabs are summed separately (the split-K is modality-aligned): their
     // dot product / norms / sign agreement are the reference's per-step gradient diagnostics
-    f32x4v gi0 = {0.f, 0.f, 0.f, 0.f}, gi1 = gi0, gt0 = gi0, gt1 = gi0;
+    f32x4v gi = {0.f, 0.f, 0.f, 0.f}, gt = gi;
+    f32x4v p0 = gi, m0 = gi, v0 = gi;
+    const bool upd = live && grad_out == nullptr;
+    if (upd) {                                               // issued before the slab sums: more bytes in flight per thread
+        p0 = *reinterpret_cast<f32x4v*>(p + i);
+        m0 = *reinterpret_cast<f32x4v*>(m + i);
+        if (o.kind != UMLH_OPT_SGD) v0 = *reinterpret_cast<f32x4v*>(v + i);
+    }
     if (live) {
-        for (int s = 0; s < dg.n_slabs_img; ++s) {
-            const float* q = slabs + (size_t)s * slab_stride + i;
-            gi0 += *reinterpret_cast<const f32x4v*>(q);
-            gi1 += *reinterpret_cast<const f32x4v*>(q + 4);
-        }
-        for (int s = dg.n_slabs_img; s < n_slabs; ++s) {
-            const float* q = slabs + (size_t)s * slab_stride + i;
-            gt0 += *reinterpret_cast<const f32x4v*>(q);
-            gt1 += *reinterpret_cast<const f32x4v*>(q + 4);
-        }
+        for (int s = 0; s < dg.n_slabs_img; ++s) gi += *reinterpret_cast<const f32x4v*>(slabs + (size_t)s * slab_stride + i);
+        for (int s = dg.n_slabs_img; s < n_slabs; ++s) gt += *reinterpret_cast<const f32x4v*>(slabs + (size_t)s * slab_stride + i);
     }
     if (dg.dst != nullptr) {                                 // uniform over the grid
         float dot = 0.f, n2i = 0.f, n2t = 0.f, agree = 0.f;
         if (live) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = (j < 4 ? gi0[j & 3] : gi1[j & 3]) * dg.inv_w0;
-                const float b = (j < 4 ? gt0[j & 3] : gt1[j & 3]) * dg.inv_w1;
+            for (int j = 0; j < 4; ++j) {
+                const float a = gi[j] * dg.inv_w0;
+                const float b = gt[j] * dg.inv_w1;
                 dot = __builtin_fmaf(a, b, dot);
                 n2i = __builtin_fmaf(a, a, n2i);
                 n2t = __builtin_fmaf(b, b, n2t);
@@ -655,33 +656,26 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
         }
     }
     if (!live) return;
-    const f32x4v g0 = gi0 + gt0, g1 = gi1 + gt1;
+    const f32x4v g0 = gi + gt;
     if (grad_out != nullptr) {             // data-parallel split: gradient only, the update follows the all-reduce
         *reinterpret_cast<f32x4v*>(grad_out + i) = g0;
-        *reinterpret_cast<f32x4v*>(grad_out + i + 4) = g1;
         return;
     }
-    f32x4v p0 = *reinterpret_cast<f32x4v*>(p + i), p1 = *reinterpret_cast<f32x4v*>(p + i + 4);
-    f32x4v m0 = *reinterpret_cast<f32x4v*>(m + i), m1 = *reinterpret_cast<f32x4v*>(m + i + 4);
-    f32x4v v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-    if (o.kind != UMLH_OPT_SGD) { v0 = *reinterpret_cast<f32x4v*>(v + i); v1 = *reinterpret_cast<f32x4v*>(v + i + 4); }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float a = p0[j], b = m0[j], c = v0[j];
         opt_update(o, g0[j], a, b, c);
         p0[j] = a; m0[j] = b; v0[j] = c;
-        a = p1[j]; b = m1[j]; c = v1[j];
-        opt_update(o, g1[j], a, b, c);
-        p1[j] = a; m1[j] = b; v1[j] = c;
     }
-    *reinterpret_cast<f32x4v*>(p + i) = p0; *reinterpret_cast<f32x4v*>(p + i + 4) = p1;
-    *reinterpret_cast<f32x4v*>(m + i) = m0; *reinterpret_cast<f32x4v*>(m + i + 4) = m1;
-    if (o.kind != UMLH_OPT_SGD) { *reinterpret_cast<f32x4v*>(v + i) = v0; *reinterpret_cast<f32x4v*>(v + i + 4) = v1; }
+    *reinterpret_cast<f32x4v*>(p + i) = p0;
+    *reinterpret_cast<f32x4v*>(m + i) = m0;
+    if (o.kind != UMLH_OPT_SGD) *reinterpret_cast<f32x4v*>(v + i) = v0;
     if (shadow != nullptr) {
         const int cls = (int)(i / K), k = (int)(i % K);
         const long long piece = ((long long)(k >> 4) * (cpad / 32) + (cls >> 5)) * 64 + (cls & 31) + 32 * ((k >> 3) & 1);
-        u32x4s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3]), pack_bf16x2(p1[0], p1[1]), pack_bf16x2(p1[2], p1[3])};
-        *reinterpret_cast<u32x4s*>(shadow + piece * 8) = w;
+        typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+        const u32x2s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3])};
+        *reinterpret_cast<u32x2s*>(shadow + piece * 8 + (k & 7)) = w;
     }
 }
 
@@ -849,8 +843,8 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
 int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
                           float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out,
                           const DiagArgs* dg, hipStream_t stream) {
-    long long n8 = (long long)C * K / 8;
-    int blocks = (int)((n8 + 255) / 256) + 1;                 // + the finalize block
+    long long n4 = (long long)C * K / 4;
+    int blocks = (int)((n4 + 255) / 256) + 1;                 // + the finalize block
     DiagArgs d;
     if (dg) d = *dg; else { d.dst = nullptr; d.n_slabs_img = n_slabs; d.inv_w0 = d.inv_w1 = 0.f; }
     if (d.n_slabs_img > n_slabs) d.n_slabs_img = n_slabs;
