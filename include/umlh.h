@@ -325,6 +325,28 @@ int  umlh_attention_forward(const float* qkv, const int64_t* lengths, int32_t T,
 int  umlh_attention_backward(const float* qkv, const int64_t* lengths, const float* lse, const float* dctx, int32_t T, int32_t B,
                              int32_t Z, int32_t H, float p, uint64_t seed, float* dqkv, void* stream);
 
+/* One whole post-norm nn.TransformerEncoderLayer (MultiBench/models.py:57-60: d_model = Z, nhead = H, dim_feedforward = d_ff,
+ * relu, dropout p, causal + key-padding mask), forward / backward, as ONE call each: the launch sequence the host mirror
+ * used to drive op by op is enqueued from C (same kernels, same arithmetic, same dropout seeds: seed for the attention
+ * probabilities, seed+1 / +2 / +3 for dropout1 / the FFN dropout / dropout2).
+ *   params[12] = in_proj_weight [3Z,Z], in_proj_bias, out_proj.weight [Z,Z], out_proj.bias, linear1.weight [d_ff,Z],
+ *                linear1.bias, linear2.weight [Z,d_ff], linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias
+ *   h_in / h_out [T*B, Z] token rows m = t*B + b;  saved: caller buffer of umlh_encoder_layer_saved_floats(cfg) floats that
+ *   the backward of the same layer reads;  scratch: umlh_encoder_layer_scratch_floats(cfg) floats, reusable across layers.
+ *   backward: dh_out = d loss / d h_out -> grads[12] (same order and shapes as params) and dh_in. */
+typedef struct {
+    int32_t T, B, Z, H, d_ff;
+    float   p, eps;
+    uint64_t seed;
+} umlh_enc_layer_t;
+uint64_t umlh_encoder_layer_saved_floats(const umlh_enc_layer_t* cfg);
+uint64_t umlh_encoder_layer_scratch_floats(const umlh_enc_layer_t* cfg);
+int  umlh_encoder_layer_forward(const umlh_enc_layer_t* cfg, const float* const* params, const float* h_in, const int64_t* lengths,
+                                float* saved, float* scratch, float* h_out, void* stream);
+int  umlh_encoder_layer_backward(const umlh_enc_layer_t* cfg, const float* const* params, const float* h_in, const int64_t* lengths,
+                                 const float* saved, const float* dh_out, float* scratch, float* const* grads, float* dh_in,
+                                 void* stream);
+
 /* A pseudo-random permutation of 0..n-1 written as int64 (device), keyed by seed: 4-round Feistel
  * network + cycle walking, no sort.  Epoch shuffles for throughput runs; NOT the reference's
  * sampler order (that is reproduced host-side by the loader, finetune.py:370-371). */
@@ -336,6 +358,11 @@ int  umlh_random_permutation(int64_t n, uint64_t seed, int64_t* out, void* strea
 int  umlh_optimizer_step(int32_t optimizer, float* param, const float* grad, float* m, float* v, int64_t n,
                          double lr, int64_t step, double beta1, double beta2, double eps, double momentum,
                          double weight_decay, void* stream);
+/* The same update for MANY parameter tensors in one launch per 48 tensors (optimizer.step() over all 70 tensors of the
+ * MultiBench model, MultiBench/main.py:122): host arrays of n_tensors device pointers / element counts; v may be NULL for SGD. */
+int  umlh_optimizer_step_multi(int32_t optimizer, int32_t n_tensors, float* const* params, const float* const* grads,
+                               float* const* m, float* const* v, const int64_t* n, double lr, int64_t step, double beta1,
+                               double beta2, double eps, double momentum, double weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -503,6 +503,35 @@ int umlh_optimizer_step(int32_t optimizer, float* param, const float* grad, floa
     return UMLH_OK;
 }
 
+extern "C" int umlh_launch_multi_opt(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* cnt,
+                                     const OptArgs* o, hipStream_t stream);
+
+int umlh_optimizer_step_multi(int32_t optimizer, int32_t n_tensors, float* const* params, const float* const* grads, float* const* m,
+                              float* const* v, const int64_t* n, double lr, int64_t step, double beta1, double beta2, double eps,
+                              double momentum, double weight_decay, void* stream) {
+    if (optimizer < UMLH_OPT_SGD || optimizer > UMLH_OPT_ADAMW) return fail(UMLH_E_INVALID, "umlh_optimizer_step_multi: unknown optimizer %d", optimizer);
+    if (n_tensors < 0 || (n_tensors > 0 && (!params || !grads || !m || !n || (optimizer != UMLH_OPT_SGD && !v))))
+        return fail(UMLH_E_INVALID, "umlh_optimizer_step_multi: null argument");
+    umlh_config_t c;
+    memset(&c, 0, sizeof(c));
+    c.optimizer = optimizer; c.beta1 = beta1; c.beta2 = beta2; c.eps = eps; c.momentum = momentum; c.weight_decay = weight_decay;
+    umlh_hyper_t hy;
+    memset(&hy, 0, sizeof(hy));
+    hy.lr = lr; hy.step = step;
+    OptArgs o = make_opt(c, hy);
+    for (int t0 = 0; t0 < n_tensors; t0 += UMLH_MULTI_OPT_MAX) {
+        const int k = n_tensors - t0 < UMLH_MULTI_OPT_MAX ? n_tensors - t0 : UMLH_MULTI_OPT_MAX;
+        long long cnt[UMLH_MULTI_OPT_MAX];
+        for (int i = 0; i < k; ++i) {
+            if (!params[t0 + i] || !grads[t0 + i] || !m[t0 + i] || n[t0 + i] < 0 || (optimizer != UMLH_OPT_SGD && !v[t0 + i]))
+                return fail(UMLH_E_INVALID, "umlh_optimizer_step_multi: tensor %d has a null buffer", t0 + i);
+            cnt[i] = n[t0 + i];
+        }
+        HIPCHK(umlh_launch_multi_opt(k, params + t0, grads + t0, m + t0, v ? v + t0 : nullptr, cnt, &o, (hipStream_t)stream), "optimizer step (multi)");
+    }
+    return UMLH_OK;
+}
+
 extern "C" {
 int umlh_seq_launch_fwd(const float* z, const float* w, const float* b, const float* x, const int64_t* lengths, int B, int T,
                         int Z, int D, float* recon, float* dres, float* row_partial, float* loss_cnt, hipStream_t st);

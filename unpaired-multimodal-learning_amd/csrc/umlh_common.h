@@ -7,6 +7,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+constexpr int UMLH_MULTI_OPT_MAX = 48;     // tensors per multi-tensor optimizer launch (descriptor table travels as a kernel argument)
+
 // K elements staged per LDS chunk in the fp32 kernels (8 MFMA k-steps of 2).
 constexpr int KT = 16;
 

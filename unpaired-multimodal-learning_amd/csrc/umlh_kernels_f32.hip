@@ -540,6 +540,30 @@ __global__ __launch_bounds__(256) void reduce_update(const float* __restrict__ s
 }
 
 // --------------------------------------------------------------------------- //
+// optimizer.step() over many parameter tensors in one launch: workgroup b works on tensor t with blk0[t] <= b < blk0[t+1]
+// --------------------------------------------------------------------------- //
+struct MultiOptArgs {
+    float* p[UMLH_MULTI_OPT_MAX]; const float* g[UMLH_MULTI_OPT_MAX]; float* m[UMLH_MULTI_OPT_MAX]; float* v[UMLH_MULTI_OPT_MAX];
+    long long n[UMLH_MULTI_OPT_MAX];
+    int blk0[UMLH_MULTI_OPT_MAX + 1];
+    int n_tensors;
+};
+
+__global__ __launch_bounds__(256) void multi_opt_kernel(MultiOptArgs a, OptArgs o) {
+    int t = 0;
+    for (int i = 1; i < a.n_tensors; ++i) t = (int)blockIdx.x >= a.blk0[i] ? i : t;
+    const long long i0 = ((long long)((int)blockIdx.x - a.blk0[t]) * 256 + threadIdx.x) * 4;
+    const long long n = a.n[t];
+    float* p = a.p[t]; const float* g = a.g[t]; float* m = a.m[t]; float* v = a.v[t];
+    for (long long e = i0; e < n && e < i0 + 4; ++e) {
+        float pp = p[e], mm = m[e], vv = o.kind != UMLH_OPT_SGD ? v[e] : 0.f;
+        opt_update(o, g[e], pp, mm, vv);
+        p[e] = pp; m[e] = mm;
+        if (o.kind != UMLH_OPT_SGD) v[e] = vv;
+    }
+}
+
+// --------------------------------------------------------------------------- //
 // per-step scalars + logit-scale parameters
 // --------------------------------------------------------------------------- //
 __device__ __forceinline__ void finalize_body(const FinalizeArgs& f, float (*sh)[256]) {
@@ -837,6 +861,22 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
     else
         hipLaunchKernelGGL((reduce_update<1>), dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, n,
                            grad_out, p, m, v, *o);
+    return (int)hipGetLastError();
+}
+
+int umlh_launch_multi_opt(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* cnt,
+                          const OptArgs* o, hipStream_t stream) {
+    MultiOptArgs a;
+    a.n_tensors = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        a.p[i] = p[i]; a.g[i] = g[i]; a.m[i] = m[i]; a.v[i] = v ? v[i] : nullptr; a.n[i] = cnt[i];
+        a.blk0[i] = blocks;
+        blocks += (int)((cnt[i] + 1023) / 1024);
+    }
+    a.blk0[n] = blocks;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(multi_opt_kernel, dim3(blocks), dim3(256), 0, stream, a, *o);
     return (int)hipGetLastError();
 }
 

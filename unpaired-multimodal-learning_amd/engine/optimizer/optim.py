@@ -66,15 +66,18 @@ class HeadOptimizer:
         import umlh
         g = self.param_groups[0]
         self.step_count += 1
-        for p in g["params"]:
-            if p.grad is None:
-                continue
+        live = [p for p in g["params"] if p.grad is not None]
+        if not live:
+            return
+        ms, vs = [], []
+        for p in live:
             st = self.state_for(p)
-            m = st["momentum_buffer"] if self.name == "sgd" else st["exp_avg"]
-            v = None if self.name == "sgd" else st["exp_avg_sq"]
-            umlh.optimizer_step(self.name, p.data, p.grad, m, v, lr=g["lr"], step=self.step_count,
-                                weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"],
-                                momentum=g["momentum"])
+            ms.append(st["momentum_buffer"] if self.name == "sgd" else st["exp_avg"])
+            vs.append(None if self.name == "sgd" else st["exp_avg_sq"])
+        # every parameter tensor in one multi-tensor launch (umlh_optimizer_step_multi): the MultiBench model has 70
+        umlh.optimizer_step_multi(self.name, [p.data for p in live], [p.grad for p in live], ms, vs, lr=g["lr"],
+                                  step=self.step_count, weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"],
+                                  momentum=g["momentum"])
 
     def state_dict(self):
         params = self.param_groups[0]["params"]

@@ -113,6 +113,15 @@ def _ln_bwd(dy, s, gamma, mean, rstd):
 N_LAYER_PARAMS = 12   # in_w, in_b, out_w, out_b, w1, b1, w2, b2, g1, be1, g2, be2
 
 
+def _layer_cfg(T, B, Z, H, dff, p, eps, seed):
+    from umlh._lib import EncLayer
+    return EncLayer(int(T), int(B), int(Z), int(H), int(dff), float(p), float(eps), int(seed) & (2 ** 64 - 1))
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class EncoderFn(torch.autograd.Function):
     """x [B,T,F] -> conv -> (+pos) -> layers -> output rows.  ``cfg`` = dict(T, B, H, p, eps, seed, out_mode)
     with out_mode 'last_len' | 'last' | 'all'; ``params`` = conv_w | None, pos [T,Z] | None, then 12 tensors per layer."""
@@ -141,24 +150,28 @@ class EncoderFn(torch.autograd.Function):
         Z = h.shape[1]
         if pos is not None:
             check(lib.umlh_add_positions(_p(h), _p(_f32(pos)), T, B, Z, st), "umlh_add_positions")
-        saved = []
         n_layers = len(layer_params) // N_LAYER_PARAMS
         lp = [_f32(t) for t in layer_params]
+        # one C call per layer (umlh_encoder_layer_forward enqueues the layer's whole launch sequence); the activations the
+        # backward needs live in one caller-owned buffer per layer
+        dff = lp[4].shape[0] if n_layers else 0
+        saved, h_ins = [], []
+        if n_layers:
+            lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed)
+            n_saved, n_scr = int(lib.umlh_encoder_layer_saved_floats(C.byref(lc))), int(lib.umlh_encoder_layer_scratch_floats(C.byref(lc)))
+            if n_saved == 0:
+                raise umlh.UmlhError(f"encoder layer shape outside the kernels' envelope: T={T} Z={Z} H={H}")
+            scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
         for li in range(n_layers):
-            in_w, in_b, out_w, out_b, w1, b1, w2, b2, g1, be1, g2, be2 = lp[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS]
-            sd = seed + 7919 * li
-            qkv = linear_forward(h, in_w, in_b)                                              # [M, 3Z]
-            att = torch.empty(M, Z, dtype=torch.float32, device=dev)
-            lse = torch.empty(B * H * T, dtype=torch.float32, device=dev)
-            check(lib.umlh_attention_forward(_p(qkv), _p(lens), T, B, Z, H, float(p), C.c_uint64(sd), _p(att), _p(lse), st),
-                  "umlh_attention_forward")
-            a = _dropout_(linear_forward(att, out_w, out_b), p, sd + 1)
-            s1, x1, mean1, rstd1 = _add_ln(h, a, g1, be1, eps)
-            hid = _dropout_(linear_forward(x1, w1, b1, relu=True), p, sd + 2)               # [M, dff]
-            f = _dropout_(linear_forward(hid, w2, b2), p, sd + 3)
-            s2, x2, mean2, rstd2 = _add_ln(x1, f, g2, be2, eps)
-            saved.append((h, qkv, lse, att, s1, mean1, rstd1, x1, hid, s2, mean2, rstd2))
-            h = x2
+            P = lp[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS]
+            lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed + 7919 * li)
+            sv = torch.empty(n_saved, dtype=torch.float32, device=dev)
+            h_out = torch.empty(M, Z, dtype=torch.float32, device=dev)
+            check(lib.umlh_encoder_layer_forward(C.byref(lc), _ptr_array(P), _p(h), _p(lens), _p(sv), _p(scratch), _p(h_out), st),
+                  "umlh_encoder_layer_forward")
+            saved.append(sv)
+            h_ins.append(h)
+            h = h_out
         mode = cfg["out_mode"]
         if mode == "all":
             idx, n_out = rows_bt, M
@@ -169,7 +182,7 @@ class EncoderFn(torch.autograd.Function):
         out = torch.empty(n_out, Z, dtype=torch.float32, device=dev)
         check(lib.umlh_gather_rows(_p(h), _p(idx), n_out, Z, _p(out), 0, st), "umlh_gather_rows")
         ctx.cfg, ctx.dims = cfg, (B, T, F, Z, M, n_layers)
-        ctx.aux = (x2d, lens, rows_tb, rows_bt, idx, cw, pos is not None, lp, saved)
+        ctx.aux = (x2d, lens, rows_tb, rows_bt, idx, cw, pos is not None, lp, saved, h_ins, dff)
         ctx.need_dx = x.requires_grad
         return out.reshape(B, T, Z) if mode == "all" else out
 
@@ -178,34 +191,26 @@ class EncoderFn(torch.autograd.Function):
         lib = umlh.load_library()
         cfg = ctx.cfg
         B, T, F, Z, M, n_layers = ctx.dims
-        x2d, lens, rows_tb, rows_bt, idx, cw, has_pos, lp, saved = ctx.aux
-        H, p, seed = cfg["H"], cfg["p"], cfg["seed"]
+        x2d, lens, rows_tb, rows_bt, idx, cw, has_pos, lp, saved, h_ins, dff = ctx.aux
+        H, p, eps, seed = cfg["H"], cfg["p"], cfg["eps"], cfg["seed"]
         dev = g_out.device
         st = _st(dev)
         g = _f32(g_out).reshape(-1, Z)
         dh = torch.zeros(M, Z, dtype=torch.float32, device=dev)
         check(lib.umlh_gather_rows(_p(g), _p(idx), g.shape[0], Z, _p(dh), 1, st), "umlh_gather_rows(scatter)")
         grads = [None] * (n_layers * N_LAYER_PARAMS)
+        if n_layers:
+            lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed)
+            scratch = torch.empty(int(lib.umlh_encoder_layer_scratch_floats(C.byref(lc))), dtype=torch.float32, device=dev)
         for li in reversed(range(n_layers)):
-            in_w, in_b, out_w, out_b, w1, b1, w2, b2, g1, be1, g2, be2 = lp[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS]
-            h_in, qkv, lse, att, s1, mean1, rstd1, x1, hid, s2, mean2, rstd2 = saved[li]
-            sd = seed + 7919 * li
-            ds2, dg2, dbe2 = _ln_bwd(dh, s2, g2, mean2, rstd2)                   # s2 = x1 + f
-            df = _dropout_(ds2.clone(), p, sd + 3)
-            dhid, dw2, db2 = linear_backward(hid, w2, df)
-            _dropout_(dhid, p, sd + 2)
-            check(lib.umlh_relu_backward(_p(hid), _p(dhid), dhid.numel(), st), "umlh_relu_backward")
-            dx1, dw1, db1 = linear_backward(x1, w1, dhid)
-            _add_(dx1, ds2)                                                      # residual fan-in at x1
-            ds1, dg1, dbe1 = _ln_bwd(dx1, s1, g1, mean1, rstd1)                  # s1 = h_in + a
-            da = _dropout_(ds1.clone(), p, sd + 1)
-            datt, dow, dob = linear_backward(att, out_w, da)
-            dqkv = torch.empty(M, 3 * Z, dtype=torch.float32, device=dev)
-            check(lib.umlh_attention_backward(_p(qkv), _p(lens), _p(lse), _p(datt), T, B, Z, H, float(p), C.c_uint64(sd), _p(dqkv), st),
-                  "umlh_attention_backward")
-            dxin, dinw, dinb = linear_backward(h_in, in_w, dqkv)
-            dh = _add_(dxin, ds1)                                                # residual fan-in at the layer input
-            grads[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS] = [dinw, dinb, dow, dob, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2]
+            P = lp[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS]
+            lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed + 7919 * li)
+            G = [torch.empty_like(t) for t in P]
+            dh_in = torch.empty(M, Z, dtype=torch.float32, device=dev)
+            check(lib.umlh_encoder_layer_backward(C.byref(lc), _ptr_array(P), _p(h_ins[li]), _p(lens), _p(saved[li]), _p(dh), _p(scratch),
+                                                  _ptr_array(G), _p(dh_in), st), "umlh_encoder_layer_backward")
+            grads[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS] = G
+            dh = dh_in
         dpos = None
         if has_pos:
             dpos = torch.empty(T, Z, dtype=torch.float32, device=dev)

@@ -9,6 +9,7 @@ from ._lib import (UmlhError, build_library, lib_path, load_library, OPT_IDS, PR
                    N_SCALARS, S_LOSS_IMG, S_LOSS_TXT, S_ACC_IMG, S_ACC_TXT, S_GSCALE_IMG, S_GSCALE_TXT,
                    S_CORRECT, S_LOSS_SUM, S_GRAD_DOT, S_GRAD_N2_IMG, S_GRAD_N2_TXT, S_GRAD_AGREE, N_CORE_SCALARS)
 from .head_engine import (HeadEngine, RowBatch, column_sums, gather_rows, grad_diagnostics, optimizer_step,  # noqa: F401
+                          optimizer_step_multi,
                           random_permutation, to_bf16, train_steps_grouped)
 from .dp import DataParallelStepper  # noqa: F401,E402
 

@@ -20,7 +20,7 @@ PREC_IDS = {"fp32": 0, "bf16": 1}
 N_CORE_SCALARS = 8
 N_SCALARS = 12
 
-SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_micro.hip", "umlh_kernels_seq.hip", "umlh_kernels_enc.hip", "umlh_api.cpp"]
+SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_micro.hip", "umlh_kernels_seq.hip", "umlh_kernels_enc.hip", "umlh_api.cpp", "umlh_encoder.cpp"]
 EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_eval_rows", "umlh_project", "umlh_optimizer_step",
@@ -30,7 +30,9 @@ EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_w
            "umlh_random_permutation", "umlh_debug_buffer",
            "umlh_gemm_f32", "umlh_add_inplace", "umlh_bias_act", "umlh_relu_backward", "umlh_dropout", "umlh_colsum",
            "umlh_add_layernorm_forward", "umlh_layernorm_backward", "umlh_add_positions", "umlh_positions_backward",
-           "umlh_gather_rows", "umlh_attention_forward", "umlh_attention_backward"]
+           "umlh_gather_rows", "umlh_attention_forward", "umlh_attention_backward", "umlh_optimizer_step_multi",
+           "umlh_encoder_layer_saved_floats", "umlh_encoder_layer_scratch_floats", "umlh_encoder_layer_forward",
+           "umlh_encoder_layer_backward"]
 
 
 class UmlhError(RuntimeError):
@@ -69,6 +71,11 @@ class GroupItem(C.Structure):
     _fields_ = [("handle", C.c_void_p), ("img", C.POINTER(Stream)), ("txt", C.POINTER(Stream)),
                 ("lr", C.POINTER(C.c_double)), ("first_step", C.c_int64), ("alpha", C.c_float), ("img_alpha", C.c_float),
                 ("scalars_out", C.c_void_p)]
+
+
+class EncLayer(C.Structure):
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("Z", C.c_int32), ("H", C.c_int32), ("d_ff", C.c_int32),
+                ("p", C.c_float), ("eps", C.c_float), ("seed", C.c_uint64)]
 
 
 class Hyper(C.Structure):
@@ -150,6 +157,15 @@ def load_library():
     lib.umlh_optimizer_step.argtypes = [i32, vp, vp, vp, vp, i64, C.c_double, i64, C.c_double, C.c_double,
                                         C.c_double, C.c_double, C.c_double, vp]
     lib.umlh_to_bf16.argtypes = [vp, vp, i64, vp]
+    pv = C.POINTER(vp)
+    lib.umlh_optimizer_step_multi.argtypes = [i32, i32, pv, pv, pv, pv, C.POINTER(i64), C.c_double, i64, C.c_double, C.c_double,
+                                              C.c_double, C.c_double, C.c_double, vp]
+    lib.umlh_encoder_layer_saved_floats.restype = u64
+    lib.umlh_encoder_layer_saved_floats.argtypes = [C.POINTER(EncLayer)]
+    lib.umlh_encoder_layer_scratch_floats.restype = u64
+    lib.umlh_encoder_layer_scratch_floats.argtypes = [C.POINTER(EncLayer)]
+    lib.umlh_encoder_layer_forward.argtypes = [C.POINTER(EncLayer), pv, vp, vp, vp, vp, vp, vp]
+    lib.umlh_encoder_layer_backward.argtypes = [C.POINTER(EncLayer), pv, vp, vp, vp, vp, vp, pv, vp, vp]
     lib.umlh_train_steps.argtypes = [vp, C.POINTER(Stream), C.POINTER(Stream), i32, C.POINTER(C.c_double), i64,
                                      C.c_float, C.c_float, vp, vp]
     lib.umlh_train_steps_grouped.argtypes = [C.POINTER(GroupItem), i32, i32, vp]
@@ -167,7 +183,7 @@ def load_library():
     lib.umlh_profile_read.argtypes = [vp, C.POINTER(C.c_float)]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("umlh_last_error", "umlh_workspace_bytes"):
+        if name not in ("umlh_last_error", "umlh_workspace_bytes", "umlh_encoder_layer_saved_floats", "umlh_encoder_layer_scratch_floats"):
             fn.restype = C.c_int
     _LIB = lib
     return lib

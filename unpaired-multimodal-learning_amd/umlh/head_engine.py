@@ -458,6 +458,31 @@ def optimizer_step(name: str, param: torch.Tensor, grad: torch.Tensor, m: torch.
                                   float(weight_decay), st), "umlh_optimizer_step")
 
 
+def optimizer_step_multi(name: str, params, grads, ms, vs, *, lr: float, step: int, weight_decay: float = 0.0,
+                         betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9) -> None:
+    """``optimizer.step()`` over a list of fp32 GPU tensors in one launch per 48 tensors (``umlh_optimizer_step_multi``)."""
+    lib = _lib.load_library()
+    n = len(params)
+    if n == 0:
+        return
+    sgd = name == "sgd"
+    fixed = []
+    for i in range(n):
+        g = grads[i]
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
+        fixed.append(g)
+        for t in (params[i], g, ms[i]) + (() if sgd else (vs[i],)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != "cuda":
+                raise UmlhError("optimizer_step_multi: contiguous fp32 GPU tensors required")
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    cnt = (C.c_int64 * n)(*[p.numel() for p in params])
+    st = C.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
+    check(lib.umlh_optimizer_step_multi(OPT_IDS[name], n, arr(params), arr(fixed), arr(ms), None if sgd else arr(vs), cnt,
+                                        float(lr), int(step), float(betas[0]), float(betas[1]), float(eps), float(momentum),
+                                        float(weight_decay), st), "umlh_optimizer_step_multi")
+
+
 def to_bf16(t: torch.Tensor) -> torch.Tensor:
     """bf16 shadow (round-to-nearest-even) of an fp32 GPU tensor through ``umlh_to_bf16``."""
     lib = _lib.load_library()
