@@ -347,6 +347,16 @@ int  umlh_encoder_layer_backward(const umlh_enc_layer_t* cfg, const float* const
                                  const float* saved, const float* dh_out, float* scratch, float* const* grads, float* dh_in,
                                  void* stream);
 
+/* The whole stack of n_layers identical layers in one call each way.  P / G: 12 pointers per layer in the order above.
+ * forward: layer li reads (li ? h + (li-1)*M*Z : h0) and writes h + li*M*Z (M = T*B) and saved + li*saved_floats; its dropout
+ * streams start at cfg->seed + 7919*li.  backward: dh_out = gradient of the last layer's output, dh = two [M,Z] scratch
+ * buffers, the gradient of h0 is left in dh0. */
+int  umlh_encoder_stack_forward(const umlh_enc_layer_t* cfg, int32_t n_layers, const float* const* P, const float* h0,
+                                const int64_t* lengths, float* saved, float* scratch, float* h, void* stream);
+int  umlh_encoder_stack_backward(const umlh_enc_layer_t* cfg, int32_t n_layers, const float* const* P, const float* h0,
+                                 const int64_t* lengths, const float* saved, const float* h, const float* dh_out, float* scratch,
+                                 float* const* G, float* dh, float* dh0, void* stream);
+
 /* A pseudo-random permutation of 0..n-1 written as int64 (device), keyed by seed: 4-round Feistel
  * network + cycle walking, no sort.  Epoch shuffles for throughput runs; NOT the reference's
  * sampler order (that is reproduced host-side by the loader, finetune.py:370-371). */

@@ -47,9 +47,11 @@ def run(z, steps=30, B=32, T=50, torch_ref=False):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(5):
-        step()
-    torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 1.0:                  # >= 1 s of warm-up: the first steps run at idle clocks
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
@@ -61,7 +63,7 @@ def run(z, steps=30, B=32, T=50, torch_ref=False):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:                                   # single HIP-path config, e.g. under rocprofv3
-        run(int(sys.argv[1]), steps=10)
+        run(int(sys.argv[1]), steps=int(sys.argv[2]) if len(sys.argv) > 2 else 50)
         sys.exit(0)
     for z in (40, 300):
         run(z)

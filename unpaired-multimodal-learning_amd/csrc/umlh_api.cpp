@@ -10,6 +10,7 @@
 #include <new>
 
 #include "umlh_common.h"
+#include "umlh_enc.h"
 #include "umlh_micro.h"
 #include <mutex>
 
@@ -591,8 +592,37 @@ int umlh_gemm_f32(const float* A, const float* B, float* out, int32_t M, int32_t
     g.out = slabs; g.k_chunk = chunk; g.slab_stride = (long long)M * ldo;
     HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, ns, (hipStream_t)stream), "gemm_f32 (split-K)");
     const long long n = (long long)M * ldo;
-    if (n > 0x7fffffffLL) return fail(UMLH_E_INVALID, "umlh_gemm_f32: output too large for the split-K reduce");
-    HIPCHK(umlh_enc_launch_colsum(slabs, ns, (int)n, out, (hipStream_t)stream), "split-K reduce");
+    Epilogue none;
+    memset(&none, 0, sizeof(none));
+    HIPCHK(umlh_enc_launch_reduce_epilogue(slabs, ns, n, n, N, &none, out, (hipStream_t)stream), "split-K reduce");
+    return UMLH_OK;
+}
+
+int umlh_gemm_f32_epi(const float* A, const float* B, float* out, int M, int N, int K, int lda, int ldb, int ta, int tb,
+                      const Epilogue* epi, int splits, float* slabs, int defer, int* ns_out, hipStream_t stream) {
+    if (!A || !B || M < 1 || N < 1 || K < 1 || splits < 1 || ((defer || splits > 1) && !slabs) || (!defer && !out))
+        return fail(UMLH_E_INVALID, "gemm_f32 (epilogue): bad arguments");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = N;
+    g.alpha = 1.f; g.k_switch = K; g.k_valid1 = K;
+    const int chunk = splits == 1 ? K : (int)round_up((K + splits - 1) / splits, KT);
+    const int ns = (K + chunk - 1) / chunk;
+    g.k_chunk = chunk;
+    g.slab_stride = (long long)M * N;
+    if (ns_out) *ns_out = ns;
+    if (!defer && ns == 1) {
+        g.out = out;
+        if (epi) g.epi = *epi;
+        HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, 1, stream), "gemm_f32 (epilogue)");
+        return UMLH_OK;
+    }
+    g.out = slabs;
+    HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, ns, stream), "gemm_f32 (slabs)");
+    if (defer) return UMLH_OK;
+    Epilogue none;
+    memset(&none, 0, sizeof(none));
+    HIPCHK(umlh_enc_launch_reduce_epilogue(slabs, ns, g.slab_stride, g.slab_stride, N, epi ? epi : &none, out, stream), "split-K reduce (epilogue)");
     return UMLH_OK;
 }
 

@@ -41,6 +41,38 @@ struct FwdArgs {
     float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
 };
 
+// Elementwise tail of a dense layer of the MultiBench encoder, applied to v = alpha * sum (element (m, n), flat index
+// i = m*N + n of a dense [M, N] result) in this order:  + bias[n];  relu;  zero where gate[i] <= 0 (relu backward against the
+// saved activation);  dropout (counter mask, stream `seed`, element i);  + add[i] (residual fan-in).  All-zero = identity.
+struct Epilogue {
+    const float* bias;
+    const float* gate;
+    const float* add;
+    unsigned long long seed;
+    unsigned thresh;             // 0 = no dropout; else keep element i iff hash(seed, i) >= thresh
+    float inv_keep;
+    int   relu;
+    int   on;                    // any field set
+};
+
+// counter-based dropout mask: keep element i of stream `seed` with probability 1 - p
+__device__ __forceinline__ bool keep_elem(unsigned long long seed, unsigned long long i, unsigned thresh) {
+    unsigned long long x = seed + i * 0x9E3779B97F4A7C15ULL;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return (unsigned)(x >> 32) >= thresh;
+}
+
+__device__ __forceinline__ float epilogue_apply(const Epilogue& e, float v, long long i, int n) {
+    if (e.bias) v += e.bias[n];
+    if (e.relu) v = fmaxf(v, 0.f);
+    if (e.gate && !(e.gate[i] > 0.f)) v = 0.f;
+    if (e.thresh) v = keep_elem(e.seed, (unsigned long long)i, e.thresh) ? v * e.inv_keep : 0.f;
+    if (e.add) v += e.add[i];
+    return v;
+}
+
 // ---- generic fp32 GEMM: out[m][n] = alpha * sum_k A(m,k) * B(n,k) ----
 struct GemmArgs {
     const float* A;  const float* B;  float* out;
@@ -62,6 +94,7 @@ struct GemmArgs {
     // > 0: modality-aligned split-K -- slabs [0, nsplit1) cover k in [0, k_switch) and the rest cover
     // [k_switch, K), k_chunk rows each (image and text gradients stay in separate slabs); 0: uniform
     int   nsplit1;
+    Epilogue epi;                // applied by the kernel when the launch has ONE slab (a split-K launch leaves it to the reduce)
 };
 
 // ---- bf16-mode argument blocks (kernels in umlh_kernels_bf16.hip, filled by umlh_api.cpp) ----
@@ -110,6 +143,11 @@ struct DwArgsB {
     long long slab_stride;
     unsigned long long* stamps;  // diagnostics (UMLH_DBG_DW=16+bits): [blocks][8 waves][8] cycle stamps, else NULL
 };
+
+// one launch sums the split-K slabs / row-chunk partials of every gradient of an encoder layer (fixed order s = 0 .. ns-1)
+constexpr int UMLH_MULTI_REDUCE_MAX = 16;
+struct ReduceDesc { const float* src; float* dst; long long stride; long long n; int ns; int blk0; };
+struct MultiReduceArgs { ReduceDesc d[UMLH_MULTI_REDUCE_MAX]; int count; };
 
 struct OptArgs {
     int   kind;                  // UMLH_OPT_*

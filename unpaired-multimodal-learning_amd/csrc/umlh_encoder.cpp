@@ -1,28 +1,35 @@
 // One post-norm nn.TransformerEncoderLayer of the MultiBench shared encoder (MultiBench/models.py:39-127), forward and
-// backward, as ONE C-ABI call each: the whole launch sequence (4 dense layers, attention, 2 x add+LayerNorm, 3 dropouts,
-// their backward) is enqueued from C.  The host mirror (multibench/encoder.py) used to make each of the ~25 forward and
-// ~35 backward launches of a layer through its own ctypes call: at MOSEI sizes (z = 40, 1600 token rows) the step was
-// bound by the Python call rate (7.7 ms for ~1000 launches), not by the GPU.
+// backward, as ONE C-ABI call each, 7 + 16 launches per layer:
+//   forward   qkv GEMM (+bias) | attention | out-proj GEMM | [bias, dropout, +residual, LayerNorm] | linear1 GEMM (+bias, relu,
+//             dropout) | linear2 GEMM (split-K slabs) | [slab sum, bias, dropout, +residual, LayerNorm]
+//   backward  LayerNorm rows (ds, dropout(ds)) | LayerNorm column partials (+ db of the next dense layer) | dW slabs | dx GEMM with
+//             the relu / dropout mask in the epilogue | ... | ONE multi-reduce of every dW slab set and column partial.
+// Round-1 form was ~16 + ~40 launches (separate bias / dropout / relu / add / copy kernels, a reduce per split-K GEMM, and
+// single-block column sums of 10-30 us each): 7.0 ms per alternation step at MOSEI sizes, 5.6 ms of it kernel time
+// (profiles/r02_multibench_kernel_stats.md).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include "umlh.h"
+#include "umlh_enc.h"
 
 namespace {
 
 inline long long ru64(long long x) { return (x + 63) / 64 * 64; }
 
-// Split-K factor of the layer's GEMMs: few 64x64 output tiles and a long reduction -- one tile per CU walking K alone is
-// latency-bound, so K is cut until ~2 tiles per CU (same rule as multibench/encoder.py: _splits).
+// Split-K factor: these GEMMs have few 64x64 output tiles and are bound by the latency of the K walk (one staged chunk per
+// iteration), so K is cut until ~768 workgroups (3 per CU, co-resident) with at least 64 reduction rows each.
 int splits_for(int m, int n, int k) {
+    static const int target = [] { const char* e = getenv("UMLH_ENC_SPLIT_WGS"); return e ? atoi(e) : 768; }();
     const long long tiles = (long long)((m + 63) / 64) * ((n + 63) / 64);
-    if (k < 512 || tiles >= 512) return 1;
-    long long s = (512 + tiles - 1) / tiles;
-    if (s > 8) s = 8;
-    if (s > k / 256) s = k / 256;
+    if (k < 128 || tiles >= target) return 1;
+    long long s = (target + tiles - 1) / tiles;
+    if (s > k / 64) s = k / 64;
+    if (s > 32) s = 32;
     return (int)(s < 1 ? 1 : s);
 }
+inline int row_chunk(long long M) { long long c = (M + 63) / 64; return (int)(c < 64 ? 64 : c); }   // <= 64 row chunks of >= 64 rows
 
-struct Dims { int T, B, Z, H, F; long long M; };
+struct Dims { int T, B, Z, H, F, R, chunk; long long M; };
 
 struct Saved {           // per-layer activations kept for the backward (offsets in floats inside `saved`)
     long long qkv, lse, att, s1, mean1, rstd1, x1, hid, s2, mean2, rstd2, total;
@@ -38,22 +45,23 @@ Saved saved_layout(const Dims& d) {
     return s;
 }
 
-long long slab_floats(const Dims& d) {      // largest split-K slab set any GEMM of the layer needs (<= 8 slabs of m*n)
-    long long mx = 0;
-    auto need = [&](long long m, long long n, long long k) { long long s = splits_for((int)m, (int)n, (int)k); if (s > 1 && s * m * n > mx) mx = s * m * n; };
-    need(d.M, 3 * d.Z, d.Z); need(d.M, d.Z, d.Z); need(d.M, d.F, d.Z); need(d.M, d.Z, d.F);          // forward
-    need(d.Z, d.F, d.M); need(d.F, d.Z, d.M); need(3 * d.Z, d.Z, d.M); need(d.Z, d.Z, d.M);          // dW
-    need(d.M, d.F, d.Z); need(d.M, d.Z, d.F); need(d.M, d.Z, 3 * d.Z);                               // dx
-    return mx;
-}
+long long slab_need(long long m, long long n, long long k) { return (long long)splits_for((int)m, (int)n, (int)k) * m * n; }
 
-struct Scratch { long long a, b, c, big, qkv, slabs, total; };   // a,b,c: [M,Z]; big: [M,F]; qkv: [M,3Z]
+// a..e: [M,Z]; big: [M,F]; qkv: [M,3Z]; slabs: split-K slabs of the activation GEMMs (consumed by the next launch);
+// pw*: split-K slabs of the four weight gradients and pcol: row-chunk partials of the column sums (all live until the
+// layer's multi-reduce)
+struct Scratch { long long a, b, c, e, big, qkv, slabs, pw2, pw1, pwo, pwin, pcol, total; };
 Scratch scratch_layout(const Dims& d) {
     Scratch s;
     long long o = 0;
     auto take = [&](long long n) { long long r = o; o += ru64(n); return r; };
-    s.a = take(d.M * d.Z); s.b = take(d.M * d.Z); s.c = take(d.M * d.Z); s.big = take(d.M * d.F); s.qkv = take(d.M * 3 * d.Z);
-    s.slabs = take(slab_floats(d));
+    const long long M = d.M, Z = d.Z, F = d.F;
+    s.a = take(M * Z); s.b = take(M * Z); s.c = take(M * Z); s.e = take(M * Z); s.big = take(M * F); s.qkv = take(M * 3 * Z);
+    long long mx = 0;
+    for (long long v : {slab_need(M, 3 * Z, Z), slab_need(M, Z, Z), slab_need(M, F, Z), slab_need(M, Z, F), slab_need(M, Z, 3 * Z)}) if (v > mx) mx = v;
+    s.slabs = take(mx);
+    s.pw2 = take(slab_need(Z, F, M)); s.pw1 = take(slab_need(F, Z, M)); s.pwo = take(slab_need(Z, Z, M)); s.pwin = take(slab_need(3 * Z, Z, M));
+    s.pcol = take((long long)d.R * (6 * Z + F + 3 * Z));
     s.total = o;
     return s;
 }
@@ -62,21 +70,34 @@ bool dims_ok(const umlh_enc_layer_t* c, Dims& d) {
     if (!c || c->T < 1 || c->T > 128 || c->B < 1 || c->Z < 1 || c->H < 1 || c->Z % c->H != 0 || c->Z / c->H > 64 || c->d_ff < 1) return false;
     if (!(c->p >= 0.f && c->p < 1.f)) return false;
     d.T = c->T; d.B = c->B; d.Z = c->Z; d.H = c->H; d.F = c->d_ff; d.M = (long long)c->T * c->B;
+    d.chunk = row_chunk(d.M); d.R = (int)((d.M + d.chunk - 1) / d.chunk);
     return true;
 }
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+#define HC(expr) do { if ((expr) != 0) return UMLH_E_HIP; } while (0)
 
-// y[M,N] = act(x[M,K] w[N,K]^T + b)
-int linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu, float* slabs, void* st) {
-    RC(umlh_gemm_f32(x, w, y, M, N, K, K, K, N, 0, 0, nullptr, nullptr, 1.f, splits_for(M, N, K), slabs, st));
-    return umlh_bias_act(y, b, M, N, relu, st);
+Epilogue epi_none() { Epilogue e; memset(&e, 0, sizeof(e)); return e; }
+void epi_dropout(Epilogue& e, float p, uint64_t seed) {
+    e.thresh = umlh_enc_drop_thresh(p); e.inv_keep = umlh_enc_drop_inv_keep(p); e.seed = seed; if (e.thresh) e.on = 1;
 }
-// dx[M,K] = dy[M,N] w[N,K];  dw[N,K] = dy^T x;  db[N] = colsum(dy)
-int linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M, int N, int K, float* slabs, void* st) {
-    RC(umlh_gemm_f32(dy, x, dw, N, K, M, N, K, K, 1, 1, nullptr, nullptr, 1.f, splits_for(N, K, M), slabs, st));
-    RC(umlh_colsum(dy, M, N, db, st));
-    return umlh_gemm_f32(dy, w, dx, M, K, N, N, K, K, 0, 1, nullptr, nullptr, 1.f, splits_for(M, K, N), slabs, st);
+
+// y[M,N] = epilogue(x[M,K] w[N,K]^T)           (defer: raw slabs left in `slabs`, *ns of them)
+int dense_fwd(const float* x, const float* w, float* y, int M, int N, int K, const Epilogue& e, float* slabs, int defer, int* ns, hipStream_t st) {
+    return umlh_gemm_f32_epi(x, w, y, M, N, K, K, K, 0, 0, &e, splits_for(M, N, K), slabs, defer, ns, st);
+}
+// dx[M,K] = epilogue(dy[M,N] w[N,K])
+int dense_bwd_x(const float* dy, const float* w, float* dx, int M, int N, int K, const Epilogue& e, float* slabs, int defer, int* ns, hipStream_t st) {
+    return umlh_gemm_f32_epi(dy, w, dx, M, K, N, N, K, 0, 1, &e, splits_for(M, K, N), slabs, defer, ns, st);
+}
+// dw[N,K] = dy[M,N]^T x[M,K] as split-K slabs (one slab: written to dw directly); appends the reduction to `red`
+int dense_bwd_w(const float* dy, const float* x, float* dw, int M, int N, int K, float* slabs, MultiReduceArgs& red, hipStream_t st) {
+    int ns = 1;
+    const int sp = splits_for(N, K, M);
+    if (sp == 1) return umlh_gemm_f32_epi(dy, x, dw, N, K, M, N, K, 1, 1, nullptr, 1, nullptr, 0, &ns, st);
+    RC(umlh_gemm_f32_epi(dy, x, nullptr, N, K, M, N, K, 1, 1, nullptr, sp, slabs, 1, &ns, st));
+    red.d[red.count++] = ReduceDesc{slabs, dw, (long long)N * K, (long long)N * K, ns, 0};
+    return UMLH_OK;
 }
 
 }  // namespace
@@ -103,21 +124,33 @@ int umlh_encoder_layer_forward(const umlh_enc_layer_t* cfg, const float* const* 
     const float *in_w = P[0], *in_b = P[1], *out_w = P[2], *out_b = P[3], *w1 = P[4], *b1 = P[5], *w2 = P[6], *b2 = P[7],
                 *g1 = P[8], *be1 = P[9], *g2 = P[10], *be2 = P[11];
     float* slabs = scratch + X.slabs;
+    hipStream_t st = (hipStream_t)stream;
     const uint64_t sd = cfg->seed;
-    // x = norm1(x + dropout1(self_attn(x)))
-    RC(linear_fwd(h_in, in_w, in_b, saved + S.qkv, M, 3 * Z, Z, 0, slabs, stream));
+    const long long mz = (long long)M * Z;
+    int ns = 1;
+    // x1 = norm1(x + dropout1(self_attn(x)))
+    Epilogue e = epi_none();
+    e.bias = in_b; e.on = 1;
+    RC(dense_fwd(h_in, in_w, saved + S.qkv, M, 3 * Z, Z, e, slabs, 0, &ns, st));
     RC(umlh_attention_forward(saved + S.qkv, lengths, d.T, d.B, Z, d.H, cfg->p, sd, saved + S.att, saved + S.lse, stream));
-    float* a = scratch + X.a;
-    RC(linear_fwd(saved + S.att, out_w, out_b, a, M, Z, Z, 0, slabs, stream));
-    RC(umlh_dropout(a, (int64_t)M * Z, cfg->p, sd + 1, stream));
-    RC(umlh_add_layernorm_forward(h_in, a, g1, be1, M, Z, cfg->eps, saved + S.s1, saved + S.x1, saved + S.mean1, saved + S.rstd1, stream));
-    // x = norm2(x + dropout2(linear2(dropout(relu(linear1(x))))))
-    RC(linear_fwd(saved + S.x1, w1, b1, saved + S.hid, M, F, Z, 1, slabs, stream));
-    RC(umlh_dropout(saved + S.hid, (int64_t)M * F, cfg->p, sd + 2, stream));
-    float* f = scratch + X.b;
-    RC(linear_fwd(saved + S.hid, w2, b2, f, M, Z, F, 0, slabs, stream));
-    RC(umlh_dropout(f, (int64_t)M * Z, cfg->p, sd + 3, stream));
-    return umlh_add_layernorm_forward(saved + S.x1, f, g2, be2, M, Z, cfg->eps, saved + S.s2, h_out, saved + S.mean2, saved + S.rstd2, stream);
+    RC(dense_fwd(saved + S.att, out_w, nullptr, M, Z, Z, epi_none(), slabs, 1, &ns, st));
+    e = epi_none();
+    e.bias = out_b; e.add = h_in; e.on = 1;
+    epi_dropout(e, cfg->p, sd + 1);
+    HC(umlh_enc_launch_add_layernorm_fused(slabs, ns, mz, &e, g1, be1, M, Z, cfg->eps, saved + S.s1, saved + S.x1, saved + S.mean1,
+                                           saved + S.rstd1, st));
+    // h_out = norm2(x1 + dropout2(linear2(dropout(relu(linear1(x1))))))
+    e = epi_none();
+    e.bias = b1; e.relu = 1; e.on = 1;
+    epi_dropout(e, cfg->p, sd + 2);
+    RC(dense_fwd(saved + S.x1, w1, saved + S.hid, M, F, Z, e, slabs, 0, &ns, st));
+    RC(dense_fwd(saved + S.hid, w2, nullptr, M, Z, F, epi_none(), slabs, 1, &ns, st));
+    e = epi_none();
+    e.bias = b2; e.add = saved + S.x1; e.on = 1;
+    epi_dropout(e, cfg->p, sd + 3);
+    HC(umlh_enc_launch_add_layernorm_fused(slabs, ns, mz, &e, g2, be2, M, Z, cfg->eps, saved + S.s2, h_out, saved + S.mean2,
+                                           saved + S.rstd2, st));
+    return UMLH_OK;
 }
 
 int umlh_encoder_layer_backward(const umlh_enc_layer_t* cfg, const float* const* P, const float* h_in, const int64_t* lengths,
@@ -126,33 +159,93 @@ int umlh_encoder_layer_backward(const umlh_enc_layer_t* cfg, const float* const*
     if (!dims_ok(cfg, d) || !P || !h_in || !saved || !dh_out || !scratch || !G || !dh_in) return UMLH_E_INVALID;
     const Saved S = saved_layout(d);
     const Scratch X = scratch_layout(d);
-    const int M = (int)d.M, Z = d.Z, F = d.F;
+    const int M = (int)d.M, Z = d.Z, F = d.F, R = d.R;
     const float *in_w = P[0], *out_w = P[2], *w1 = P[4], *w2 = P[6], *g1 = P[8], *g2 = P[10];
     float *dinw = G[0], *dinb = G[1], *dow = G[2], *dob = G[3], *dw1 = G[4], *db1 = G[5], *dw2 = G[6], *db2 = G[7],
           *dg1 = G[8], *dbe1 = G[9], *dg2 = G[10], *dbe2 = G[11];
     float* slabs = scratch + X.slabs;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t sd = cfg->seed;
-    const size_t mz = sizeof(float) * (size_t)M * Z;
-    float *ds2 = scratch + X.a, *df = scratch + X.b, *dx1 = scratch + X.c, *dhid = scratch + X.big, *dqkv = scratch + X.qkv;
-    // s2 = x1 + f
-    RC(umlh_layernorm_backward(dh_out, saved + S.s2, g2, saved + S.mean2, saved + S.rstd2, M, Z, ds2, dg2, dbe2, stream));
-    if (hipMemcpyAsync(df, ds2, mz, hipMemcpyDeviceToDevice, st) != hipSuccess) return UMLH_E_HIP;
-    RC(umlh_dropout(df, (int64_t)M * Z, cfg->p, sd + 3, stream));
-    RC(linear_bwd(saved + S.hid, w2, df, dhid, dw2, db2, M, Z, F, slabs, stream));
-    RC(umlh_dropout(dhid, (int64_t)M * F, cfg->p, sd + 2, stream));
-    RC(umlh_relu_backward(saved + S.hid, dhid, (int64_t)M * F, stream));
-    RC(linear_bwd(saved + S.x1, w1, dhid, dx1, dw1, db1, M, F, Z, slabs, stream));
-    RC(umlh_add_inplace(dx1, ds2, (int64_t)M * Z, stream));                      // residual fan-in at x1
-    // s1 = h_in + a
-    float *ds1 = scratch + X.a, *da = scratch + X.b, *datt = dhid;               // ds2 / df / dhid are dead from here on
-    RC(umlh_layernorm_backward(dx1, saved + S.s1, g1, saved + S.mean1, saved + S.rstd1, M, Z, ds1, dg1, dbe1, stream));
-    if (hipMemcpyAsync(da, ds1, mz, hipMemcpyDeviceToDevice, st) != hipSuccess) return UMLH_E_HIP;
-    RC(umlh_dropout(da, (int64_t)M * Z, cfg->p, sd + 1, stream));
-    RC(linear_bwd(saved + S.att, out_w, da, datt, dow, dob, M, Z, Z, slabs, stream));
+    const long long mz = (long long)M * Z;
+    float *ds2 = scratch + X.a, *df = scratch + X.b, *dx1 = scratch + X.c, *ds1 = scratch + X.e, *dhid = scratch + X.big,
+          *dqkv = scratch + X.qkv;
+    float* pc = scratch + X.pcol;                      // column partials [R][width] each
+    float *p_g2 = pc, *p_be2 = p_g2 + (long long)R * Z, *p_b2 = p_be2 + (long long)R * Z, *p_g1 = p_b2 + (long long)R * Z,
+          *p_be1 = p_g1 + (long long)R * Z, *p_ob = p_be1 + (long long)R * Z, *p_b1 = p_ob + (long long)R * Z,
+          *p_inb = p_b1 + (long long)R * F;
+    MultiReduceArgs red;
+    memset(&red, 0, sizeof(red));
+    auto col = [&](float* part, float* dst, int width) { red.d[red.count++] = ReduceDesc{part, dst, (long long)width, (long long)width, R, 0}; };
+    int ns = 1;
+    // h_out = norm2(s2), s2 = x1 + dropout3(f): ds2, df = dropout3(ds2)
+    HC(umlh_enc_launch_layernorm_bwd_rows_fused(dh_out, 1, 0, nullptr, nullptr, saved + S.s2, g2, saved + S.mean2, saved + S.rstd2, M, Z,
+                                                ds2, df, cfg->p, sd + 3, st));
+    HC(umlh_enc_launch_ln_cols_partial(dh_out, saved + S.s2, saved + S.mean2, saved + S.rstd2, df, M, Z, d.chunk, p_g2, p_be2, p_b2, st));
+    col(p_g2, dg2, Z); col(p_be2, dbe2, Z); col(p_b2, db2, Z);
+    // f = hid w2^T + b2, hid = dropout2(relu(x1 w1^T + b1))
+    RC(dense_bwd_w(df, saved + S.hid, dw2, M, Z, F, scratch + X.pw2, red, st));
+    Epilogue e = epi_none();
+    e.gate = saved + S.hid; e.on = 1;
+    epi_dropout(e, cfg->p, sd + 2);
+    RC(dense_bwd_x(df, w2, dhid, M, Z, F, e, slabs, 0, &ns, st));
+    RC(dense_bwd_w(dhid, saved + S.x1, dw1, M, F, Z, scratch + X.pw1, red, st));
+    HC(umlh_enc_launch_colsum_partial(dhid, M, F, d.chunk, p_b1, st));
+    col(p_b1, db1, F);
+    RC(dense_bwd_x(dhid, w1, nullptr, M, F, Z, epi_none(), slabs, 1, &ns, st));
+    // x1 = norm1(s1), s1 = h_in + dropout1(a): dx1 = slabs + ds2 (residual fan-in), ds1, da = dropout1(ds1)
+    float* da = df;                                    // df is dead
+    HC(umlh_enc_launch_layernorm_bwd_rows_fused(slabs, ns, mz, ds2, dx1, saved + S.s1, g1, saved + S.mean1, saved + S.rstd1, M, Z,
+                                                ds1, da, cfg->p, sd + 1, st));
+    HC(umlh_enc_launch_ln_cols_partial(dx1, saved + S.s1, saved + S.mean1, saved + S.rstd1, da, M, Z, d.chunk, p_g1, p_be1, p_ob, st));
+    col(p_g1, dg1, Z); col(p_be1, dbe1, Z); col(p_ob, dob, Z);
+    // a = att out_w^T + out_b
+    RC(dense_bwd_w(da, saved + S.att, dow, M, Z, Z, scratch + X.pwo, red, st));
+    float* datt = ds2;                                 // ds2 is dead
+    RC(dense_bwd_x(da, out_w, datt, M, Z, Z, epi_none(), slabs, 0, &ns, st));
     RC(umlh_attention_backward(saved + S.qkv, lengths, saved + S.lse, datt, d.T, d.B, Z, d.H, cfg->p, sd, dqkv, stream));
-    RC(linear_bwd(h_in, in_w, dqkv, dh_in, dinw, dinb, M, 3 * Z, Z, slabs, stream));
-    return umlh_add_inplace(dh_in, ds1, (int64_t)M * Z, stream);                 // residual fan-in at the layer input
+    // qkv = h_in in_w^T + in_b
+    RC(dense_bwd_w(dqkv, h_in, dinw, M, 3 * Z, Z, scratch + X.pwin, red, st));
+    HC(umlh_enc_launch_colsum_partial(dqkv, M, 3 * Z, d.chunk, p_inb, st));
+    col(p_inb, dinb, 3 * Z);
+    e = epi_none();
+    e.add = ds1; e.on = 1;                             // residual fan-in at the layer input
+    RC(dense_bwd_x(dqkv, in_w, dh_in, M, 3 * Z, Z, e, slabs, 0, &ns, st));
+    HC(umlh_enc_launch_multi_reduce(&red, st));
+    return UMLH_OK;
+}
+
+// the whole layer stack in one call: layer li reads (li ? h + (li-1)*M*Z : h0), writes h + li*M*Z and saved + li*saved_floats;
+// its dropout streams start at cfg->seed + 7919*li
+int umlh_encoder_stack_forward(const umlh_enc_layer_t* cfg, int32_t n_layers, const float* const* P, const float* h0,
+                               const int64_t* lengths, float* saved, float* scratch, float* h, void* stream) {
+    Dims d;
+    if (!dims_ok(cfg, d) || n_layers < 0 || !P || !h0 || !saved || !scratch || !h) return UMLH_E_INVALID;
+    const long long nsv = saved_layout(d).total, mz = d.M * d.Z;
+    umlh_enc_layer_t lc = *cfg;
+    for (int li = 0; li < n_layers; ++li) {
+        lc.seed = cfg->seed + 7919ull * (uint64_t)li;
+        RC(umlh_encoder_layer_forward(&lc, P + 12 * li, li ? h + (li - 1) * mz : h0, lengths, saved + li * nsv, scratch, h + li * mz, stream));
+    }
+    return UMLH_OK;
+}
+
+// G: 12 gradient pointers per layer; dh_out: gradient of the last layer's output; dh: two [M,Z] ping-pong buffers; the gradient
+// of h0 is left in dh0
+int umlh_encoder_stack_backward(const umlh_enc_layer_t* cfg, int32_t n_layers, const float* const* P, const float* h0,
+                                const int64_t* lengths, const float* saved, const float* h, const float* dh_out, float* scratch,
+                                float* const* G, float* dh, float* dh0, void* stream) {
+    Dims d;
+    if (!dims_ok(cfg, d) || n_layers < 1 || !P || !h0 || !saved || !h || !dh_out || !scratch || !G || !dh || !dh0) return UMLH_E_INVALID;
+    const long long nsv = saved_layout(d).total, mz = d.M * d.Z;
+    umlh_enc_layer_t lc = *cfg;
+    const float* g = dh_out;
+    for (int li = n_layers - 1; li >= 0; --li) {
+        lc.seed = cfg->seed + 7919ull * (uint64_t)li;
+        float* out = li == 0 ? dh0 : dh + (li & 1) * mz;
+        RC(umlh_encoder_layer_backward(&lc, P + 12 * li, li ? h + (li - 1) * mz : h0, lengths, saved + li * nsv, g, scratch, G + 12 * li, out, stream));
+        g = out;
+    }
+    return UMLH_OK;
 }
 
 }  // extern "C"

@@ -16,13 +16,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// counter-based dropout mask: keep element i of stream `seed` with probability 1 - p
-__device__ __forceinline__ bool keep_elem(unsigned long long seed, unsigned long long i, unsigned thresh) {
-    unsigned long long x = seed + i * 0x9E3779B97F4A7C15ULL;
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
-    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
-    x ^= x >> 31;
-    return (unsigned)(x >> 32) >= thresh;
+// sum_s p[s*stride], s = 0 .. ns-1 in that order; the loads go out 8 at a time (a plain `v += p[s*stride]` loop waits for
+// each load before issuing the next: 25 slabs cost 25 memory latencies)
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, long long stride, int ns) {
+    float v = 0.f;
+    for (int s = 0; s < ns; s += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (s + u < ns) ? p[(size_t)(s + u) * stride] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    return v;
 }
 
 // y[m][n] = act(y[m][n] + b[n])
@@ -59,8 +64,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     __shared__ float sh[CG][64];
     const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6;
     float s = 0.f;
-    if (c < N)
-        for (int m = g; m < M; m += CG) s += x[(size_t)m * N + c];
+    if (c < N) s = slab_sum(x + (size_t)g * N + c, (long long)CG * N, (M - g + CG - 1) / CG);
     sh[g][l] = s;
     __syncthreads();
     if (g == 0 && c < N) {
@@ -205,6 +209,9 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
     float* Vs = Ks + (size_t)T * rs;
     float* Ps = Vs + (size_t)T * rs;                   // [AW][T]
     const float scale = rsqrtf((float)dh);
+    int dhp = 1;
+    while (dhp < dh) dhp <<= 1;                        // the P.V product spreads the keys over G = 64/dhp lane groups
+    const int G = 64 / dhp, dl = lane & (dhp - 1), grp = lane / dhp;
     for (int i = threadIdx.x; i < T * dh; i += 256) {
         int j = i / dh, d = i % dh;
         const float* row = qkv + ((size_t)j * B + b) * 3 * Z + h * dh + d;
@@ -242,11 +249,11 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < dh) {
-            float o = 0.f;
-            for (int j = 0; j < jmax; ++j) o = __builtin_fmaf(P[j], Vs[j * rs + lane], o);
-            ctx[((size_t)t * B + b) * Z + h * dh + lane] = jmax > 0 ? o / l : 0.f;
-        }
+        float o = 0.f;                                  // lane = (key group, head-dim column): G partial sums per column
+        if (dl < dh)
+            for (int j = grp; j < jmax; j += G) o = __builtin_fmaf(P[j], Vs[j * rs + dl], o);
+        for (int off = dhp; off < 64; off <<= 1) o += __shfl_xor(o, off);
+        if (lane < dh) ctx[((size_t)t * B + b) * Z + h * dh + lane] = jmax > 0 ? o / l : 0.f;
         if (lane == 0) lse[hb + t] = jmax > 0 ? mx + __logf(l) : 0.f;
         __builtin_amdgcn_wave_barrier();               // P is reused by this wave's next query
     }
@@ -280,6 +287,9 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     __syncthreads();
     const int len = lengths ? (int)lengths[b] : T;
     const float scale = rsqrtf((float)dh);
+    int dhp = 1;
+    while (dhp < dh) dhp <<= 1;                        // the dq / dk / dv sums spread their terms over G = 64/dhp lane groups
+    const int G = 64 / dhp, dl = lane & (dhp - 1), grp = lane / dhp;
     // ---- phase 1: a wave per query t ----
     for (int t = wave; t < T; t += AW) {
         const int jmax = min(t + 1, len);
@@ -311,11 +321,11 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < dh) {
-            float dq = 0.f;
-            for (int j = 0; j < jmax; ++j) dq = __builtin_fmaf(S1[j], Ks[j * rs + lane], dq);
-            dqkv[((size_t)t * B + b) * 3 * Z + h * dh + lane] = dq;
-        }
+        float dq = 0.f;
+        if (dl < dh)
+            for (int j = grp; j < jmax; j += G) dq = __builtin_fmaf(S1[j], Ks[j * rs + dl], dq);
+        for (int off = dhp; off < 64; off <<= 1) dq += __shfl_xor(dq, off);
+        if (lane < dh) dqkv[((size_t)t * B + b) * 3 * Z + h * dh + lane] = dq;
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -349,17 +359,153 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < dh) {
-            float dk = 0.f, dv = 0.f;
-            for (int t = j; t < T; ++t) {
-                dk = __builtin_fmaf(S1[t], Qs[t * rs + lane], dk);
-                dv = __builtin_fmaf(S2[t], Gs[t * rs + lane], dv);
+        float dk = 0.f, dv = 0.f;
+        if (dl < dh)
+            for (int t = j + grp; t < T; t += G) {
+                dk = __builtin_fmaf(S1[t], Qs[t * rs + dl], dk);
+                dv = __builtin_fmaf(S2[t], Gs[t * rs + dl], dv);
             }
+        for (int off = dhp; off < 64; off <<= 1) { dk += __shfl_xor(dk, off); dv += __shfl_xor(dv, off); }
+        if (lane < dh) {
             float* drow = dqkv + ((size_t)j * B + b) * 3 * Z + h * dh + lane;
             drow[Z] = dk;
             drow[2 * Z] = dv;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// --------------------------------------------------------------------------- //
+// fused kernels of the layer chain (umlh_encoder.cpp): the elementwise tails (bias, relu, dropout, residual) ride in the
+// GEMM epilogue or in the row kernel that consumes the GEMM's split-K slabs; column reductions (bias / LayerNorm weight
+// gradients) are row-chunk partials that ONE multi_reduce launch per layer sums in a fixed order.
+// --------------------------------------------------------------------------- //
+// out[i] = epilogue(sum_s slabs[s*stride + i])
+__global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __restrict__ slabs, int ns, long long stride, long long total,
+                                                              int N, Epilogue e, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float v = slab_sum(slabs + i, stride, ns);
+    out[i] = e.on ? epilogue_apply(e, v, i, (int)(i % N)) : v;
+}
+
+// s = epilogue(sum of ns slabs of x) (bias, dropout, + residual through e.add); y = LayerNorm(s) * gamma + beta; a wave per row
+__global__ __launch_bounds__(256) void add_layernorm_fused_kernel(const float* __restrict__ x, int ns, long long stride, Epilogue e,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int M, int N, float eps, float* __restrict__ s_out,
+                                                                  float* __restrict__ y, float* __restrict__ mean_out,
+                                                                  float* __restrict__ rstd_out) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const size_t o = (size_t)m * N;
+    float sum = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        float v = slab_sum(x + o + n, stride, ns);
+        v = epilogue_apply(e, v, (long long)(o + n), n);
+        s_out[o + n] = v;
+        sum += v;
+    }
+    const float mean = wave_sum(sum) / (float)N;
+    float var = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        float d = s_out[o + n] - mean;          // written by this lane above
+        var += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(var) / (float)N + eps);
+    for (int n = lane; n < N; n += 64) y[o + n] = (s_out[o + n] - mean) * rstd * gamma[n] + beta[n];
+    if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+}
+
+// dy = sum of ns slabs (+ add: the gradient arriving over the residual path), kept in dy_out when it had to be formed here;
+// ds = LayerNorm backward of the row; dsd = dropout(ds) on stream `seed` (the branch gradient), NULL = not wanted
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_fused_kernel(const float* __restrict__ dy, int ns, long long stride,
+                                                                       const float* __restrict__ add, float* __restrict__ dy_out,
+                                                                       const float* __restrict__ s, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                       int M, int N, float* __restrict__ ds, float* __restrict__ dsd,
+                                                                       unsigned thresh, float inv_keep, unsigned long long seed) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const size_t o = (size_t)m * N;
+    const float mu = mean[m], rs = rstd[m];
+    const float* dyr = dy_out ? dy_out : dy;
+    float a = 0.f, b = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        float d;
+        if (dy_out) {
+            d = slab_sum(dy + o + n, stride, ns);
+            if (add) d += add[o + n];
+            dy_out[o + n] = d;
+        } else d = dy[o + n];
+        const float g = gamma[n] * d, xh = (s[o + n] - mu) * rs;
+        a += g;
+        b += g * xh;
+    }
+    a = wave_sum(a) / (float)N;
+    b = wave_sum(b) / (float)N;
+    for (int n = lane; n < N; n += 64) {
+        const float g = gamma[n] * dyr[o + n], xh = (s[o + n] - mu) * rs;
+        const float v = rs * (g - a - xh * b);
+        ds[o + n] = v;
+        if (dsd) dsd[o + n] = (thresh == 0 || keep_elem(seed, (unsigned long long)(o + n), thresh)) ? v * inv_keep : 0.f;
+    }
+}
+
+// part[r][n] = sum of x[m][n] over the rows m of chunk r = blockIdx.y (4 row groups x 64 columns per block, fixed order)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int M, int N, int chunk,
+                                                             float* __restrict__ part) {
+    __shared__ float sh[4][64];
+    const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * chunk, m1 = min(M, m0 + chunk);
+    float t = 0.f;
+    if (c < N)
+        for (int m = m0 + g; m < m1; m += 4) t += x[(size_t)m * N + c];
+    sh[g][l] = t;
+    __syncthreads();
+    if (g == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+}
+
+// row-chunk partials of dgamma = sum dy*xhat, dbeta = sum dy and (dsd != NULL) of the following dense layer's db = sum dsd
+__global__ __launch_bounds__(256) void ln_cols_partial_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ dsd, int M, int N, int chunk,
+                                                              float* __restrict__ part_g, float* __restrict__ part_b,
+                                                              float* __restrict__ part_d) {
+    __shared__ float sh[3][4][64];
+    const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * chunk, m1 = min(M, m0 + chunk);
+    float a = 0.f, b = 0.f, d3 = 0.f;
+    if (c < N)
+        for (int m = m0 + g; m < m1; m += 4) {
+            const float d = dy[(size_t)m * N + c];
+            a += d * (s[(size_t)m * N + c] - mean[m]) * rstd[m];
+            b += d;
+            if (dsd) d3 += dsd[(size_t)m * N + c];
+        }
+    sh[0][g][l] = a; sh[1][g][l] = b; sh[2][g][l] = d3;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        const size_t o = (size_t)blockIdx.y * N + c;
+        part_g[o] = (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]);
+        part_b[o] = (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]);
+        if (dsd) part_d[o] = (sh[2][0][l] + sh[2][1][l]) + (sh[2][2][l] + sh[2][3][l]);
+    }
+}
+
+// dst[i] = sum_s src[s*stride + i] for every entry of the table: all partial sums of a layer's backward in one launch
+__global__ __launch_bounds__(256) void multi_reduce_kernel(MultiReduceArgs a) {
+    int t = 0;
+#pragma unroll 1
+    while (t + 1 < a.count && (int)blockIdx.x >= a.d[t + 1].blk0) ++t;
+    const ReduceDesc d = a.d[t];
+    const long long base = (long long)((int)blockIdx.x - d.blk0) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long i = base + 256 * q;
+        if (i < d.n) {
+            d.dst[i] = slab_sum(d.src + i, d.stride, d.ns);
+        }
     }
 }
 
@@ -414,6 +560,59 @@ int umlh_enc_launch_layernorm_bwd(const float* dy, const float* s, const float* 
     hipLaunchKernelGGL(layernorm_bwd_cols_kernel, dim3((N + 63) / 64), dim3(64 * CG), 0, st, dy, s, mean, rstd, M, N, dgamma, dbeta);
     return (int)hipGetLastError();
 }
+
+
+int umlh_enc_launch_reduce_epilogue(const float* slabs, int ns, long long stride, long long total, int N, const Epilogue* e, float* out,
+                                    hipStream_t st) {
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(blocks_for(total)), dim3(256), 0, st, slabs, ns, stride, total, N, *e, out);
+    return (int)hipGetLastError();
+}
+
+int umlh_enc_launch_add_layernorm_fused(const float* x, int ns, long long stride, const Epilogue* e, const float* gamma,
+                                        const float* beta, int M, int N, float eps, float* s_out, float* y, float* mean, float* rstd,
+                                        hipStream_t st) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(add_layernorm_fused_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, ns, stride, *e, gamma, beta, M, N, eps,
+                       s_out, y, mean, rstd);
+    return (int)hipGetLastError();
+}
+
+int umlh_enc_launch_layernorm_bwd_rows_fused(const float* dy, int ns, long long stride, const float* add, float* dy_out, const float* s,
+                                             const float* gamma, const float* mean, const float* rstd, int M, int N, float* ds,
+                                             float* dsd, float p, unsigned long long seed, hipStream_t st) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_bwd_rows_fused_kernel, dim3((M + 3) / 4), dim3(256), 0, st, dy, ns, stride, add, dy_out, s, gamma, mean,
+                       rstd, M, N, ds, dsd, drop_thresh(p), p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+    return (int)hipGetLastError();
+}
+
+int umlh_enc_launch_colsum_partial(const float* x, int M, int N, int chunk, float* part, hipStream_t st) {
+    if (M <= 0 || N <= 0) return 0;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, (M + chunk - 1) / chunk), dim3(256), 0, st, x, M, N, chunk, part);
+    return (int)hipGetLastError();
+}
+
+int umlh_enc_launch_ln_cols_partial(const float* dy, const float* s, const float* mean, const float* rstd, const float* dsd, int M, int N,
+                                    int chunk, float* part_g, float* part_b, float* part_d, hipStream_t st) {
+    if (M <= 0 || N <= 0) return 0;
+    hipLaunchKernelGGL(ln_cols_partial_kernel, dim3((N + 63) / 64, (M + chunk - 1) / chunk), dim3(256), 0, st, dy, s, mean, rstd, dsd, M, N,
+                       chunk, part_g, part_b, part_d);
+    return (int)hipGetLastError();
+}
+
+// fills blk0 of every entry; entries with n == 0 are allowed
+int umlh_enc_launch_multi_reduce(MultiReduceArgs* a, hipStream_t st) {
+    if (a->count < 1 || a->count > UMLH_MULTI_REDUCE_MAX) return (int)hipErrorInvalidValue;
+    int blocks = 0;
+    for (int t = 0; t < a->count; ++t) { a->d[t].blk0 = blocks; blocks += (int)((a->d[t].n + 1023) / 1024); }
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(blocks), dim3(256), 0, st, *a);
+    return (int)hipGetLastError();
+}
+
+float umlh_enc_drop_inv_keep(float p) { return p > 0.f ? 1.f / (1.f - p) : 1.f; }
+unsigned umlh_enc_drop_thresh(float p) { return drop_thresh(p); }
 
 int umlh_enc_launch_add_pos(float* x, const float* pos, int T, int B, int Z, hipStream_t st) {
     hipLaunchKernelGGL(add_pos_kernel, dim3(blocks_for((long long)T * B * Z)), dim3(256), 0, st, x, pos, T, B, Z);

@@ -487,7 +487,11 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 int m = m0 + wm * 32 * TM + i * 32 + acc_row(e, h);
-                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][j][e] * alpha;
+                if (m < g.M) {
+                    float v = acc[i][j][e] * alpha;
+                    if (g.epi.on && gridDim.z == 1) v = epilogue_apply(g.epi, v, (long long)m * g.ldo + n, n);   // dense result: ldo == N
+                    out[(size_t)m * g.ldo + n] = v;
+                }
             }
         }
 }

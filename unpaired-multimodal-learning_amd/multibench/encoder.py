@@ -37,12 +37,13 @@ def _f32(t):
 
 
 def _splits(m, n, k):
-    """Split-K factor: these GEMMs have few 64x64 output tiles (z <= 300) and a long reduction (1600 token rows or
-    the 2048-wide FFN); one tile per CU walking K alone is latency-bound, so K is cut until ~2 tiles per CU."""
+    """Split-K factor (same rule as csrc/umlh_encoder.cpp: splits_for): these GEMMs have few 64x64 output tiles
+    (z <= 300) and a long reduction (1600 token rows or the 2048-wide FFN) whose walk is latency-bound, so K is cut
+    until ~768 workgroups with at least 64 reduction rows each."""
     tiles = ((m + 63) // 64) * ((n + 63) // 64)
-    if k < 512 or tiles >= 512:
+    if k < 128 or tiles >= 768:
         return 1
-    return max(1, min(8, k // 256, -(-512 // tiles)))
+    return max(1, min(32, k // 64, -(-768 // tiles)))
 
 
 def gemm(a, b, m, n, k, lda, ldb, ta, tb, a_rows=None, k_rows=None, alpha=1.0):
@@ -152,26 +153,22 @@ class EncoderFn(torch.autograd.Function):
             check(lib.umlh_add_positions(_p(h), _p(_f32(pos)), T, B, Z, st), "umlh_add_positions")
         n_layers = len(layer_params) // N_LAYER_PARAMS
         lp = [_f32(t) for t in layer_params]
-        # one C call per layer (umlh_encoder_layer_forward enqueues the layer's whole launch sequence); the activations the
-        # backward needs live in one caller-owned buffer per layer
+        # one C call for the layer stack (umlh_encoder_stack_forward enqueues every layer's launch sequence); the activations
+        # the backward needs live in one caller-owned buffer
         dff = lp[4].shape[0] if n_layers else 0
-        saved, h_ins = [], []
+        saved = hs = None
+        h0 = h
         if n_layers:
             lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed)
             n_saved, n_scr = int(lib.umlh_encoder_layer_saved_floats(C.byref(lc))), int(lib.umlh_encoder_layer_scratch_floats(C.byref(lc)))
             if n_saved == 0:
                 raise umlh.UmlhError(f"encoder layer shape outside the kernels' envelope: T={T} Z={Z} H={H}")
             scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
-        for li in range(n_layers):
-            P = lp[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS]
-            lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed + 7919 * li)
-            sv = torch.empty(n_saved, dtype=torch.float32, device=dev)
-            h_out = torch.empty(M, Z, dtype=torch.float32, device=dev)
-            check(lib.umlh_encoder_layer_forward(C.byref(lc), _ptr_array(P), _p(h), _p(lens), _p(sv), _p(scratch), _p(h_out), st),
-                  "umlh_encoder_layer_forward")
-            saved.append(sv)
-            h_ins.append(h)
-            h = h_out
+            saved = torch.empty(n_layers * n_saved, dtype=torch.float32, device=dev)
+            hs = torch.empty(n_layers, M, Z, dtype=torch.float32, device=dev)
+            check(lib.umlh_encoder_stack_forward(C.byref(lc), n_layers, _ptr_array(lp), _p(h0), _p(lens), _p(saved), _p(scratch), _p(hs), st),
+                  "umlh_encoder_stack_forward")
+            h = hs[n_layers - 1]
         mode = cfg["out_mode"]
         if mode == "all":
             idx, n_out = rows_bt, M
@@ -182,7 +179,7 @@ class EncoderFn(torch.autograd.Function):
         out = torch.empty(n_out, Z, dtype=torch.float32, device=dev)
         check(lib.umlh_gather_rows(_p(h), _p(idx), n_out, Z, _p(out), 0, st), "umlh_gather_rows")
         ctx.cfg, ctx.dims = cfg, (B, T, F, Z, M, n_layers)
-        ctx.aux = (x2d, lens, rows_tb, rows_bt, idx, cw, pos is not None, lp, saved, h_ins, dff)
+        ctx.aux = (x2d, lens, rows_tb, rows_bt, idx, cw, pos is not None, lp, saved, h0, hs, dff)
         ctx.need_dx = x.requires_grad
         return out.reshape(B, T, Z) if mode == "all" else out
 
@@ -191,7 +188,7 @@ class EncoderFn(torch.autograd.Function):
         lib = umlh.load_library()
         cfg = ctx.cfg
         B, T, F, Z, M, n_layers = ctx.dims
-        x2d, lens, rows_tb, rows_bt, idx, cw, has_pos, lp, saved, h_ins, dff = ctx.aux
+        x2d, lens, rows_tb, rows_bt, idx, cw, has_pos, lp, saved, h0, hs, dff = ctx.aux
         H, p, eps, seed = cfg["H"], cfg["p"], cfg["eps"], cfg["seed"]
         dev = g_out.device
         st = _st(dev)
@@ -202,15 +199,15 @@ class EncoderFn(torch.autograd.Function):
         if n_layers:
             lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed)
             scratch = torch.empty(int(lib.umlh_encoder_layer_scratch_floats(C.byref(lc))), dtype=torch.float32, device=dev)
-        for li in reversed(range(n_layers)):
-            P = lp[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS]
-            lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed + 7919 * li)
-            G = [torch.empty_like(t) for t in P]
-            dh_in = torch.empty(M, Z, dtype=torch.float32, device=dev)
-            check(lib.umlh_encoder_layer_backward(C.byref(lc), _ptr_array(P), _p(h_ins[li]), _p(lens), _p(saved[li]), _p(dh), _p(scratch),
-                                                  _ptr_array(G), _p(dh_in), st), "umlh_encoder_layer_backward")
-            grads[li * N_LAYER_PARAMS:(li + 1) * N_LAYER_PARAMS] = G
-            dh = dh_in
+            flat = torch.empty(sum(t.numel() for t in lp), dtype=torch.float32, device=dev)       # one allocation for every gradient
+            grads, o = [], 0
+            for t in lp:
+                grads.append(flat[o:o + t.numel()].view(t.shape))
+                o += t.numel()
+            tmp = torch.empty(3, M, Z, dtype=torch.float32, device=dev)                         # 2 ping-pong buffers + the result
+            check(lib.umlh_encoder_stack_backward(C.byref(lc), n_layers, _ptr_array(lp), _p(h0), _p(lens), _p(saved), _p(hs), _p(dh),
+                                                  _p(scratch), _ptr_array(grads), _p(tmp), _p(tmp[2]), st), "umlh_encoder_stack_backward")
+            dh = tmp[2]
         dpos = None
         if has_pos:
             dpos = torch.empty(T, Z, dtype=torch.float32, device=dev)

@@ -185,7 +185,7 @@ class UML(nn.Module):
 
     def forward(self, x, y, x_lengths=None, y_lengths=None):
         dev = (x if x is not None else y).device
-        loss_x = loss_y = torch.tensor(0.0, device=dev)
+        loss_x = loss_y = torch.zeros((), device=dev)          # a fill kernel: torch.tensor(0.0, device=...) is a blocking host copy
         x_proj = y_proj = zx = zy = x_recon = y_recon = diff_next_x = diff_next_y = None
         if x is not None:
             x, x_proj, zx, x_recon, loss_x, diff_next_x = self._branch(x, self.xproj_in, self.decoders[0], x_lengths,
@@ -194,7 +194,7 @@ class UML(nn.Module):
             # the reference encodes y WITHOUT a key-padding mask (models.py:233) but masks its loss
             y, y_proj, zy, y_recon, loss_y, diff_next_y = self._branch(y, self.yproj_in, self.decoders[1], y_lengths,
                                                                         None, self.infoNCE_loss)
-        loss_private = torch.tensor(0.0, device=dev)
+        loss_private = torch.zeros((), device=dev)
         x_private = y_private = None
         if x is not None and y is not None:
             x_private, y_private = x_proj - zx, y_proj - zy

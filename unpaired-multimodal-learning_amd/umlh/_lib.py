@@ -32,7 +32,7 @@ EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_w
            "umlh_add_layernorm_forward", "umlh_layernorm_backward", "umlh_add_positions", "umlh_positions_backward",
            "umlh_gather_rows", "umlh_attention_forward", "umlh_attention_backward", "umlh_optimizer_step_multi",
            "umlh_encoder_layer_saved_floats", "umlh_encoder_layer_scratch_floats", "umlh_encoder_layer_forward",
-           "umlh_encoder_layer_backward"]
+           "umlh_encoder_layer_backward", "umlh_encoder_stack_forward", "umlh_encoder_stack_backward"]
 
 
 class UmlhError(RuntimeError):
@@ -166,6 +166,8 @@ def load_library():
     lib.umlh_encoder_layer_scratch_floats.argtypes = [C.POINTER(EncLayer)]
     lib.umlh_encoder_layer_forward.argtypes = [C.POINTER(EncLayer), pv, vp, vp, vp, vp, vp, vp]
     lib.umlh_encoder_layer_backward.argtypes = [C.POINTER(EncLayer), pv, vp, vp, vp, vp, vp, pv, vp, vp]
+    lib.umlh_encoder_stack_forward.argtypes = [C.POINTER(EncLayer), i32, pv, vp, vp, vp, vp, vp, vp]
+    lib.umlh_encoder_stack_backward.argtypes = [C.POINTER(EncLayer), i32, pv, vp, vp, vp, vp, vp, vp, pv, vp, vp, vp]
     lib.umlh_train_steps.argtypes = [vp, C.POINTER(Stream), C.POINTER(Stream), i32, C.POINTER(C.c_double), i64,
                                      C.c_float, C.c_float, vp, vp]
     lib.umlh_train_steps_grouped.argtypes = [C.POINTER(GroupItem), i32, i32, vp]
