@@ -274,12 +274,15 @@ int  umlh_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
  * z [B,T,Z], w [D,Z], bias [D], x [B,T,D] fp32 device; lengths int64[B] device or NULL.
  * recon [B,T,D] optional; dres [B*T*D] and row_partial [B*T] scratch that the backward reads;
  * loss_cnt device float[2] = {loss, denominator}.  Backward: grad_out device scalar (d/d loss);
- * dz [B,T,Z], dw [D,Z], db [D]. */
+ * dz [B,T,Z], dw [D,Z], db [D]; scratch: umlh_seq_mse_backward_scratch_floats(B,T,Z,D) device floats for the split-K
+ * slabs of dW and the row-chunk partials of db (NULL: one workgroup walks all B*T rows per output tile). */
 int  umlh_seq_mse_forward(const float* z, const float* w, const float* bias, const float* x, const int64_t* lengths,
                           int32_t B, int32_t T, int32_t Z, int32_t D, float* recon, float* dres, float* row_partial,
                           float* loss_cnt, void* stream);
 int  umlh_seq_mse_backward(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out,
-                           int32_t B, int32_t T, int32_t Z, int32_t D, float* dz, float* dw, float* db, void* stream);
+                           int32_t B, int32_t T, int32_t Z, int32_t D, float* dz, float* dw, float* db, float* scratch,
+                           void* stream);
+uint64_t umlh_seq_mse_backward_scratch_floats(int32_t B, int32_t T, int32_t Z, int32_t D);
 
 /* ---- MultiBench shared encoder (MultiBench/models.py:39-127: Conv1d k=1 -> positions -> 5 x post-norm
  * nn.TransformerEncoderLayer(z, nhead, dim_feedforward=2048, relu, dropout) under a causal + key-padding
@@ -338,6 +341,8 @@ typedef struct {
     int32_t T, B, Z, H, d_ff;
     float   p, eps;
     uint64_t seed;
+    const uint64_t* seed_device;   /* optional device word added to `seed` by every kernel (NULL = none): lets a launch sequence
+                                    * captured in a HIP graph draw fresh dropout masks at every replay */
 } umlh_enc_layer_t;
 uint64_t umlh_encoder_layer_saved_floats(const umlh_enc_layer_t* cfg);
 uint64_t umlh_encoder_layer_scratch_floats(const umlh_enc_layer_t* cfg);
@@ -356,6 +361,29 @@ int  umlh_encoder_stack_forward(const umlh_enc_layer_t* cfg, int32_t n_layers, c
 int  umlh_encoder_stack_backward(const umlh_enc_layer_t* cfg, int32_t n_layers, const float* const* P, const float* h0,
                                  const int64_t* lengths, const float* saved, const float* h, const float* dh_out, float* scratch,
                                  float* const* G, float* dh, float* dh0, void* stream);
+
+/* Encoder plan: the layer stack bound to fixed buffers so that its launch sequences replay from HIP graphs (one graph launch per
+ * forward / backward instead of 7 + 16 kernel launches per layer: at MOSEI sizes the alternation step is bound by the host's
+ * launch rate).  The caller owns `workspace` (umlh_encoder_plan_floats(cfg, n_layers) device floats, alive as long as the plan)
+ * and the parameter tensors P (12 per layer; their ADDRESSES are baked into the graphs -- make a new plan when they move).
+ * Buffers inside the workspace (float offsets from umlh_encoder_plan_offsets):
+ *   [0] h0 [T*B, Z]    input token rows, written by the caller before forward
+ *   [1] lengths        int64[B] key-padding lengths (has_lengths != 0), written by the caller before forward
+ *   [2] h_last [T*B,Z] output of the last layer
+ *   [3] dh_out [T*B,Z] gradient of h_last, written by the caller before backward
+ *   [4] dh0 [T*B, Z]   gradient of h0 after backward
+ *   [5] grads          gradients of all parameters after backward, flat in P order
+ * forward: seed = base of this pass's dropout streams (cfg->seed is ignored).  The first call of each direction runs the plain
+ * launch sequence, the second captures it, later calls replay.  A plan serves ONE forward/backward pair at a time and one
+ * stream at a time. */
+typedef struct umlh_enc_plan_s* umlh_enc_plan_t;
+uint64_t umlh_encoder_plan_floats(const umlh_enc_layer_t* cfg, int32_t n_layers);
+int  umlh_encoder_plan_create(const umlh_enc_layer_t* cfg, int32_t n_layers, const float* const* P, int32_t has_lengths,
+                              float* workspace, umlh_enc_plan_t* out);
+int  umlh_encoder_plan_offsets(umlh_enc_plan_t plan, uint64_t offsets[6]);
+int  umlh_encoder_plan_forward(umlh_enc_plan_t plan, uint64_t seed, void* stream);
+int  umlh_encoder_plan_backward(umlh_enc_plan_t plan, void* stream);
+void umlh_encoder_plan_destroy(umlh_enc_plan_t plan);
 
 /* A pseudo-random permutation of 0..n-1 written as int64 (device), keyed by seed: 4-round Feistel
  * network + cycle walking, no sort.  Epoch shuffles for throughput runs; NOT the reference's

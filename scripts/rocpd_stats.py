@@ -26,5 +26,23 @@ def main():
             print("%-40s grid %4d x %3d x %3d  %6.1f/step avg %7.2f us min %7.2f" % (r[0][:40], r[1], r[2], r[3], r[4] / steps, r[5] / 1e3, r[6] / 1e3))
 
 
+def timeline(db, per, iters=10):
+    """Average duration of each of the last `per`-kernel periods, in dispatch order (SEQ=<kernels per iteration>)."""
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, grid_x/workgroup_x, grid_y/workgroup_y, grid_z/workgroup_z, start, end from kernels order by start").fetchall()
+    seq = rows[len(rows) - per * iters:]
+    tot = 0.0
+    for i in range(per):
+        d = sum(seq[it * per + i][5] - seq[it * per + i][4] for it in range(iters)) / iters
+        r = seq[i]
+        print("%2d %-60s %4dx%3dx%3d %7.2f us" % (i, r[0][:60], r[1], r[2], r[3], d / 1e3))
+        tot += d
+    print("sum %.2f us" % (tot / 1e3))
+
+
 if __name__ == "__main__":
+    if os.environ.get("SEQ"):
+        src = sys.argv[1]
+        timeline(src if src.endswith(".db") else glob.glob(os.path.join(src, "**", "*.db"), recursive=True)[0], int(os.environ["SEQ"]))
+        sys.exit(0)
     main()

@@ -117,3 +117,49 @@ def test_encoder_dropout_is_consistent_between_forward_and_backward():
     o1 = EncoderFn.apply(x, lengths, cfg, m.conv.weight, m.pos_embedding.weight[:T], *params)
     o2 = EncoderFn.apply(x, lengths, cfg2, m.conv.weight, m.pos_embedding.weight[:T], *params)
     assert (o1 - o2).abs().max().item() > 1e-3
+
+
+def test_encoder_plan_graph_replay_equals_plain_launches():
+    """The layer stack runs on a plan whose launch sequences are captured into HIP graphs on their second use: the eager
+    call, the capturing call and the replays give bit-identical outputs and gradients for the same dropout seed, a new
+    seed changes the masks of a replay, and two live forwards of the same configuration get different plans."""
+    from multibench import encoder as E
+    from multibench.models import Transformer
+    torch.manual_seed(3)
+    B, T, F, Z = 6, 11, 7, 40
+    m = Transformer(F, Z, nhead=5, num_layers=3, pos_embd=True, pos_learnable=False).to(DEV)
+    x = torch.randn(B, T, F, device=DEV)
+    lengths = torch.randint(2, T + 1, (B,), device=DEV)
+    params = [t for layer in m.transformer.layers for t in E.layer_params(layer)]
+    w = torch.randn(B, Z, device=DEV)
+
+    def run(seed):
+        for p in m.parameters():
+            p.grad = None
+        cfg = {"H": 5, "p": 0.1, "eps": 1e-5, "seed": seed, "out_mode": "last_len"}
+        xi = x.clone().requires_grad_(True)
+        out = E.EncoderFn.apply(xi, lengths, cfg, m.conv.weight, m.pos_table[:T], *params)
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return [out.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in params]
+    E._PLANS.clear()
+    runs = [run(42) for _ in range(4)]                      # eager, capture + launch, replay, replay
+    assert len(E._PLANS) == 1 and len(next(iter(E._PLANS.values()))) == 1
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
+    other = run(43)
+    assert (other[0] - runs[0][0]).abs().max().item() > 1e-4
+    assert all(torch.isfinite(t).all() for t in other)
+    # two forwards alive at once: the second must not reuse the first one's plan (its saved activations are still needed)
+    cfg = {"H": 5, "p": 0.0, "eps": 1e-5, "seed": 0, "out_mode": "last_len"}
+    x1, x2 = x.clone().requires_grad_(True), (2 * x).clone().requires_grad_(True)
+    o1 = E.EncoderFn.apply(x1, lengths, cfg, m.conv.weight, m.pos_table[:T], *params)
+    o2 = E.EncoderFn.apply(x2, lengths, cfg, m.conv.weight, m.pos_table[:T], *params)
+    (o1 * w).sum().backward()
+    g1 = x1.grad.clone()
+    del o1, o2
+    x3 = x.clone().requires_grad_(True)
+    (E.EncoderFn.apply(x3, lengths, cfg, m.conv.weight, m.pos_table[:T], *params) * w).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(g1, x3.grad)

@@ -20,6 +20,7 @@ int umlh_micro_launch(int nch, int cw, const UmlhMicroHead* heads, int n_heads, 
 int umlh_f32_fwd_config(int C, int* ctw, int* wc);
 int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t stream);
 int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream);
+int umlh_f32_launch_gemm_enc(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream);
 int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long long slab_stride, long long n,
                               float* grad_out, float* p, float* m, float* v, const OptArgs* o, hipStream_t stream);
 int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream);
@@ -50,9 +51,9 @@ int umlh_enc_launch_add_pos(float* x, const float* pos, int T, int B, int Z, hip
 int umlh_enc_launch_pos_grad(const float* dx, int T, int B, int Z, float* dpos, hipStream_t st);
 int umlh_enc_launch_gather_rows(const float* x, const int64_t* idx, int n, int Z, float* out, int scatter, hipStream_t st);
 int umlh_enc_launch_attention_fwd(const float* qkv, const int64_t* lengths, int T, int B, int Z, int H, float p,
-                                  unsigned long long seed, float* ctx, float* lse, hipStream_t st);
+                                  unsigned long long seed, const unsigned long long* seed_ptr, float* ctx, float* lse, hipStream_t st);
 int umlh_enc_launch_attention_bwd(const float* qkv, const int64_t* lengths, const float* lse, const float* dctx, int T, int B,
-                                  int Z, int H, float p, unsigned long long seed, float* dqkv, hipStream_t st);
+                                  int Z, int H, float p, unsigned long long seed, const unsigned long long* seed_ptr, float* dqkv, hipStream_t st);
 int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, void* dst, int mode, hipStream_t stream);
 }
 
@@ -537,7 +538,7 @@ extern "C" {
 int umlh_seq_launch_fwd(const float* z, const float* w, const float* b, const float* x, const int64_t* lengths, int B, int T,
                         int Z, int D, float* recon, float* dres, float* row_partial, float* loss_cnt, hipStream_t st);
 int umlh_seq_launch_bwd(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out, int B,
-                        int T, int Z, int D, float* dz, float* dw, float* db, hipStream_t st);
+                        int T, int Z, int D, float* dz, float* dw, float* db, int with_params, hipStream_t st);
 }
 
 int umlh_seq_mse_forward(const float* z, const float* w, const float* bias, const float* x, const int64_t* lengths, int32_t B,
@@ -549,11 +550,49 @@ int umlh_seq_mse_forward(const float* z, const float* w, const float* bias, cons
     return UMLH_OK;
 }
 
+// split-K factor / row chunking of the decoder gradient: dW [D,Z] over B*T rows (same rule as the encoder layers)
+static int seq_splits(int D, int Z, int R) {
+    const long long tiles = (long long)((D + 63) / 64) * ((Z + 63) / 64);
+    long long s = (768 + tiles - 1) / tiles;
+    if (s > R / 64) s = R / 64;
+    if (s > 32) s = 32;
+    return (int)(s < 1 ? 1 : s);
+}
+static int seq_row_chunk(int R) { int c = (R + 63) / 64; return c < 64 ? 64 : c; }
+
+uint64_t umlh_seq_mse_backward_scratch_floats(int32_t B, int32_t T, int32_t Z, int32_t D) {
+    if (B < 1 || T < 1 || Z < 1 || D < 1) return 0;
+    const int R = B * T, chunk = seq_row_chunk(R);
+    return (uint64_t)seq_splits(D, Z, R) * D * Z + (uint64_t)((R + chunk - 1) / chunk) * D + 64;
+}
+
 int umlh_seq_mse_backward(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out,
-                          int32_t B, int32_t T, int32_t Z, int32_t D, float* dz, float* dw, float* db, void* stream) {
+                          int32_t B, int32_t T, int32_t Z, int32_t D, float* dz, float* dw, float* db, float* scratch, void* stream) {
     if (!z || !w || !dres || !loss_cnt || !grad_out || !dz || !dw || !db) return fail(UMLH_E_INVALID, "umlh_seq_mse_backward: null buffer");
     if (B < 1 || T < 1 || Z < 1 || D < 1 || D > 8192) return fail(UMLH_E_INVALID, "umlh_seq_mse_backward: bad shape");
-    HIPCHK(umlh_seq_launch_bwd(z, w, dres, loss_cnt, grad_out, B, T, Z, D, dz, dw, db, (hipStream_t)stream), "seq bwd");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = B * T, sp = seq_splits(D, Z, R);
+    if (!scratch || sp == 1) {
+        HIPCHK(umlh_seq_launch_bwd(z, w, dres, loss_cnt, grad_out, B, T, Z, D, dz, dw, db, 1, st), "seq bwd");
+        return UMLH_OK;
+    }
+    // dz as before; dW[d][k] = s * sum_r dres[r][d] z[r][k] as split-K slabs, db[d] = s * sum_r dres[r][d] as row-chunk partials,
+    // both summed and scaled (s = 2 * grad_out / denominator, device-side) by one multi-reduce
+    HIPCHK(umlh_seq_launch_bwd(z, w, dres, loss_cnt, grad_out, B, T, Z, D, dz, dw, db, 0, st), "seq bwd (dz)");
+    const int chunk = seq_row_chunk(R), nr = (R + chunk - 1) / chunk;
+    float* slabs = scratch;
+    float* part = scratch + (size_t)sp * D * Z;
+    int ns = 1;
+    int rc = umlh_gemm_f32_epi(dres, z, nullptr, D, Z, R, D, Z, 1, 1, nullptr, sp, slabs, 1, &ns, st);
+    if (rc) return rc;
+    HIPCHK(umlh_enc_launch_colsum_partial(dres, R, D, chunk, part, st), "seq bwd (db partials)");
+    MultiReduceArgs red;
+    memset(&red, 0, sizeof(red));
+    red.d[0] = ReduceDesc{slabs, dw, (long long)D * Z, (long long)D * Z, ns, 0};
+    red.d[1] = ReduceDesc{part, db, (long long)D, (long long)D, nr, 0};
+    red.count = 2;
+    red.s_num = grad_out; red.s_den = loss_cnt + 1; red.s_mul = 2.f;
+    HIPCHK(umlh_enc_launch_multi_reduce(&red, st), "seq bwd (reduce)");
     return UMLH_OK;
 }
 
@@ -582,15 +621,18 @@ int umlh_gemm_f32(const float* A, const float* B, float* out, int32_t M, int32_t
     g.A = A; g.B = B; g.a_rows = a_rows; g.k_rows = k_rows;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldo = ldo;
     g.alpha = alpha; g.k_switch = K; g.k_valid1 = K;
+    // dense operands and a short K range per workgroup: the latency-oriented kernel (see gemm_enc)
+    const bool dense = !a_rows && !k_rows && !(ta == 1 && tb == 0) && (K + splits - 1) / splits <= 512;
+    auto launch = dense ? umlh_f32_launch_gemm_enc : umlh_f32_launch_gemm;
     if (splits == 1) {
         g.out = out; g.k_chunk = K; g.slab_stride = 0;
-        HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, 1, (hipStream_t)stream), "gemm_f32");
+        HIPCHK(launch(&g, ta, tb, 1, (hipStream_t)stream), "gemm_f32");
         return UMLH_OK;
     }
     const int chunk = (int)round_up((K + splits - 1) / splits, KT);
     const int ns = (K + chunk - 1) / chunk;
     g.out = slabs; g.k_chunk = chunk; g.slab_stride = (long long)M * ldo;
-    HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, ns, (hipStream_t)stream), "gemm_f32 (split-K)");
+    HIPCHK(launch(&g, ta, tb, ns, (hipStream_t)stream), "gemm_f32 (split-K)");
     const long long n = (long long)M * ldo;
     Epilogue none;
     memset(&none, 0, sizeof(none));
@@ -611,14 +653,16 @@ int umlh_gemm_f32_epi(const float* A, const float* B, float* out, int M, int N, 
     g.k_chunk = chunk;
     g.slab_stride = (long long)M * N;
     if (ns_out) *ns_out = ns;
+    static const bool legacy = [] { const char* e = getenv("UMLH_ENC_GEMM"); return e && atoi(e) == 0; }();   // timing comparisons
+    auto launch = legacy ? umlh_f32_launch_gemm : umlh_f32_launch_gemm_enc;
     if (!defer && ns == 1) {
         g.out = out;
         if (epi) g.epi = *epi;
-        HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, 1, stream), "gemm_f32 (epilogue)");
+        HIPCHK(launch(&g, ta, tb, 1, stream), "gemm_enc (epilogue)");
         return UMLH_OK;
     }
     g.out = slabs;
-    HIPCHK(umlh_f32_launch_gemm(&g, ta, tb, ns, stream), "gemm_f32 (slabs)");
+    HIPCHK(launch(&g, ta, tb, ns, stream), "gemm_enc (slabs)");
     if (defer) return UMLH_OK;
     Epilogue none;
     memset(&none, 0, sizeof(none));
@@ -695,7 +739,7 @@ int umlh_attention_forward(const float* qkv, const int64_t* lengths, int32_t T, 
     if (!qkv || !ctx || !lse || B < 1 || !(p >= 0.f && p < 1.f)) return fail(UMLH_E_INVALID, "umlh_attention_forward: bad arguments");
     if (T < 1 || T > 128 || H < 1 || Z % H != 0 || Z / H > 64)
         return fail(UMLH_E_INVALID, "umlh_attention_forward: T=%d Z=%d H=%d outside the kernel's envelope (T <= 128, Z/H <= 64)", T, Z, H);
-    HIPCHK(umlh_enc_launch_attention_fwd(qkv, lengths, T, B, Z, H, p, seed, ctx, lse, (hipStream_t)stream), "attention_fwd");
+    HIPCHK(umlh_enc_launch_attention_fwd(qkv, lengths, T, B, Z, H, p, seed, nullptr, ctx, lse, (hipStream_t)stream), "attention_fwd");
     return UMLH_OK;
 }
 
@@ -705,7 +749,7 @@ int umlh_attention_backward(const float* qkv, const int64_t* lengths, const floa
         return fail(UMLH_E_INVALID, "umlh_attention_backward: bad arguments");
     if (T < 1 || T > 128 || H < 1 || Z % H != 0 || Z / H > 64)
         return fail(UMLH_E_INVALID, "umlh_attention_backward: T=%d Z=%d H=%d outside the kernel's envelope", T, Z, H);
-    HIPCHK(umlh_enc_launch_attention_bwd(qkv, lengths, lse, dctx, T, B, Z, H, p, seed, dqkv, (hipStream_t)stream), "attention_bwd");
+    HIPCHK(umlh_enc_launch_attention_bwd(qkv, lengths, lse, dctx, T, B, Z, H, p, seed, nullptr, dqkv, (hipStream_t)stream), "attention_bwd");
     return UMLH_OK;
 }
 

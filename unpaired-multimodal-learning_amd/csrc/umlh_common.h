@@ -49,6 +49,7 @@ struct Epilogue {
     const float* gate;
     const float* add;
     unsigned long long seed;
+    const unsigned long long* seed_ptr;   // optional device word added to `seed` (launch sequences replayed from a HIP graph)
     unsigned thresh;             // 0 = no dropout; else keep element i iff hash(seed, i) >= thresh
     float inv_keep;
     int   relu;
@@ -68,7 +69,7 @@ __device__ __forceinline__ float epilogue_apply(const Epilogue& e, float v, long
     if (e.bias) v += e.bias[n];
     if (e.relu) v = fmaxf(v, 0.f);
     if (e.gate && !(e.gate[i] > 0.f)) v = 0.f;
-    if (e.thresh) v = keep_elem(e.seed, (unsigned long long)i, e.thresh) ? v * e.inv_keep : 0.f;
+    if (e.thresh) v = keep_elem(e.seed + (e.seed_ptr ? *e.seed_ptr : 0ull), (unsigned long long)i, e.thresh) ? v * e.inv_keep : 0.f;
     if (e.add) v += e.add[i];
     return v;
 }
@@ -147,7 +148,10 @@ struct DwArgsB {
 // one launch sums the split-K slabs / row-chunk partials of every gradient of an encoder layer (fixed order s = 0 .. ns-1)
 constexpr int UMLH_MULTI_REDUCE_MAX = 16;
 struct ReduceDesc { const float* src; float* dst; long long stride; long long n; int ns; int blk0; };
-struct MultiReduceArgs { ReduceDesc d[UMLH_MULTI_REDUCE_MAX]; int count; };
+struct MultiReduceArgs {
+    ReduceDesc d[UMLH_MULTI_REDUCE_MAX]; int count;
+    const float* s_num; const float* s_den; float s_mul;   // s_num != NULL: every sum is scaled by s_mul * s_num[0] / s_den[0]
+};
 
 struct OptArgs {
     int   kind;                  // UMLH_OPT_*

@@ -11,11 +11,16 @@ int umlh_enc_launch_add_layernorm_fused(const float* x, int ns, long long stride
                                         hipStream_t st);
 int umlh_enc_launch_layernorm_bwd_rows_fused(const float* dy, int ns, long long stride, const float* add, float* dy_out, const float* s,
                                              const float* gamma, const float* mean, const float* rstd, int M, int N, float* ds,
-                                             float* dsd, float p, unsigned long long seed, hipStream_t st);
+                                             float* dsd, float p, unsigned long long seed, const unsigned long long* seed_ptr, hipStream_t st);
 int umlh_enc_launch_colsum_partial(const float* x, int M, int N, int chunk, float* part, hipStream_t st);
 int umlh_enc_launch_ln_cols_partial(const float* dy, const float* s, const float* mean, const float* rstd, const float* dsd, int M, int N,
                                     int chunk, float* part_g, float* part_b, float* part_d, hipStream_t st);
 int umlh_enc_launch_multi_reduce(MultiReduceArgs* a, hipStream_t st);
+int umlh_enc_launch_attention_fwd(const float* qkv, const int64_t* lengths, int T, int B, int Z, int H, float p,
+                                  unsigned long long seed, const unsigned long long* seed_ptr, float* ctx, float* lse, hipStream_t st);
+int umlh_enc_launch_attention_bwd(const float* qkv, const int64_t* lengths, const float* lse, const float* dctx, int T, int B,
+                                  int Z, int H, float p, unsigned long long seed, const unsigned long long* seed_ptr, float* dqkv, hipStream_t st);
+int umlh_enc_launch_set_u64(unsigned long long* dst, unsigned long long v, hipStream_t st);
 float umlh_enc_drop_inv_keep(float p);
 unsigned umlh_enc_drop_thresh(float p);
 

@@ -8,7 +8,9 @@
 // single-block column sums of 10-30 us each): 7.0 ms per alternation step at MOSEI sizes, 5.6 ms of it kernel time
 // (profiles/r02_multibench_kernel_stats.md).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include "umlh.h"
 #include "umlh_enc.h"
 
@@ -78,8 +80,8 @@ bool dims_ok(const umlh_enc_layer_t* c, Dims& d) {
 #define HC(expr) do { if ((expr) != 0) return UMLH_E_HIP; } while (0)
 
 Epilogue epi_none() { Epilogue e; memset(&e, 0, sizeof(e)); return e; }
-void epi_dropout(Epilogue& e, float p, uint64_t seed) {
-    e.thresh = umlh_enc_drop_thresh(p); e.inv_keep = umlh_enc_drop_inv_keep(p); e.seed = seed; if (e.thresh) e.on = 1;
+void epi_dropout(Epilogue& e, float p, uint64_t seed, const unsigned long long* seed_ptr) {
+    e.thresh = umlh_enc_drop_thresh(p); e.inv_keep = umlh_enc_drop_inv_keep(p); e.seed = seed; e.seed_ptr = seed_ptr; if (e.thresh) e.on = 1;
 }
 
 // y[M,N] = epilogue(x[M,K] w[N,K]^T)           (defer: raw slabs left in `slabs`, *ns of them)
@@ -126,28 +128,29 @@ int umlh_encoder_layer_forward(const umlh_enc_layer_t* cfg, const float* const* 
     float* slabs = scratch + X.slabs;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t sd = cfg->seed;
+    const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(cfg->seed_device);
     const long long mz = (long long)M * Z;
     int ns = 1;
     // x1 = norm1(x + dropout1(self_attn(x)))
     Epilogue e = epi_none();
     e.bias = in_b; e.on = 1;
     RC(dense_fwd(h_in, in_w, saved + S.qkv, M, 3 * Z, Z, e, slabs, 0, &ns, st));
-    RC(umlh_attention_forward(saved + S.qkv, lengths, d.T, d.B, Z, d.H, cfg->p, sd, saved + S.att, saved + S.lse, stream));
+    HC(umlh_enc_launch_attention_fwd(saved + S.qkv, lengths, d.T, d.B, Z, d.H, cfg->p, sd, sp, saved + S.att, saved + S.lse, st));
     RC(dense_fwd(saved + S.att, out_w, nullptr, M, Z, Z, epi_none(), slabs, 1, &ns, st));
     e = epi_none();
     e.bias = out_b; e.add = h_in; e.on = 1;
-    epi_dropout(e, cfg->p, sd + 1);
+    epi_dropout(e, cfg->p, sd + 1, sp);
     HC(umlh_enc_launch_add_layernorm_fused(slabs, ns, mz, &e, g1, be1, M, Z, cfg->eps, saved + S.s1, saved + S.x1, saved + S.mean1,
                                            saved + S.rstd1, st));
     // h_out = norm2(x1 + dropout2(linear2(dropout(relu(linear1(x1))))))
     e = epi_none();
     e.bias = b1; e.relu = 1; e.on = 1;
-    epi_dropout(e, cfg->p, sd + 2);
+    epi_dropout(e, cfg->p, sd + 2, sp);
     RC(dense_fwd(saved + S.x1, w1, saved + S.hid, M, F, Z, e, slabs, 0, &ns, st));
     RC(dense_fwd(saved + S.hid, w2, nullptr, M, Z, F, epi_none(), slabs, 1, &ns, st));
     e = epi_none();
     e.bias = b2; e.add = saved + S.x1; e.on = 1;
-    epi_dropout(e, cfg->p, sd + 3);
+    epi_dropout(e, cfg->p, sd + 3, sp);
     HC(umlh_enc_launch_add_layernorm_fused(slabs, ns, mz, &e, g2, be2, M, Z, cfg->eps, saved + S.s2, h_out, saved + S.mean2,
                                            saved + S.rstd2, st));
     return UMLH_OK;
@@ -166,6 +169,7 @@ int umlh_encoder_layer_backward(const umlh_enc_layer_t* cfg, const float* const*
     float* slabs = scratch + X.slabs;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t sd = cfg->seed;
+    const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(cfg->seed_device);
     const long long mz = (long long)M * Z;
     float *ds2 = scratch + X.a, *df = scratch + X.b, *dx1 = scratch + X.c, *ds1 = scratch + X.e, *dhid = scratch + X.big,
           *dqkv = scratch + X.qkv;
@@ -179,14 +183,14 @@ int umlh_encoder_layer_backward(const umlh_enc_layer_t* cfg, const float* const*
     int ns = 1;
     // h_out = norm2(s2), s2 = x1 + dropout3(f): ds2, df = dropout3(ds2)
     HC(umlh_enc_launch_layernorm_bwd_rows_fused(dh_out, 1, 0, nullptr, nullptr, saved + S.s2, g2, saved + S.mean2, saved + S.rstd2, M, Z,
-                                                ds2, df, cfg->p, sd + 3, st));
+                                                ds2, df, cfg->p, sd + 3, sp, st));
     HC(umlh_enc_launch_ln_cols_partial(dh_out, saved + S.s2, saved + S.mean2, saved + S.rstd2, df, M, Z, d.chunk, p_g2, p_be2, p_b2, st));
     col(p_g2, dg2, Z); col(p_be2, dbe2, Z); col(p_b2, db2, Z);
     // f = hid w2^T + b2, hid = dropout2(relu(x1 w1^T + b1))
     RC(dense_bwd_w(df, saved + S.hid, dw2, M, Z, F, scratch + X.pw2, red, st));
     Epilogue e = epi_none();
     e.gate = saved + S.hid; e.on = 1;
-    epi_dropout(e, cfg->p, sd + 2);
+    epi_dropout(e, cfg->p, sd + 2, sp);
     RC(dense_bwd_x(df, w2, dhid, M, Z, F, e, slabs, 0, &ns, st));
     RC(dense_bwd_w(dhid, saved + S.x1, dw1, M, F, Z, scratch + X.pw1, red, st));
     HC(umlh_enc_launch_colsum_partial(dhid, M, F, d.chunk, p_b1, st));
@@ -195,14 +199,14 @@ int umlh_encoder_layer_backward(const umlh_enc_layer_t* cfg, const float* const*
     // x1 = norm1(s1), s1 = h_in + dropout1(a): dx1 = slabs + ds2 (residual fan-in), ds1, da = dropout1(ds1)
     float* da = df;                                    // df is dead
     HC(umlh_enc_launch_layernorm_bwd_rows_fused(slabs, ns, mz, ds2, dx1, saved + S.s1, g1, saved + S.mean1, saved + S.rstd1, M, Z,
-                                                ds1, da, cfg->p, sd + 1, st));
+                                                ds1, da, cfg->p, sd + 1, sp, st));
     HC(umlh_enc_launch_ln_cols_partial(dx1, saved + S.s1, saved + S.mean1, saved + S.rstd1, da, M, Z, d.chunk, p_g1, p_be1, p_ob, st));
     col(p_g1, dg1, Z); col(p_be1, dbe1, Z); col(p_ob, dob, Z);
     // a = att out_w^T + out_b
     RC(dense_bwd_w(da, saved + S.att, dow, M, Z, Z, scratch + X.pwo, red, st));
     float* datt = ds2;                                 // ds2 is dead
     RC(dense_bwd_x(da, out_w, datt, M, Z, Z, epi_none(), slabs, 0, &ns, st));
-    RC(umlh_attention_backward(saved + S.qkv, lengths, saved + S.lse, datt, d.T, d.B, Z, d.H, cfg->p, sd, dqkv, stream));
+    HC(umlh_enc_launch_attention_bwd(saved + S.qkv, lengths, saved + S.lse, datt, d.T, d.B, Z, d.H, cfg->p, sd, sp, dqkv, st));
     // qkv = h_in in_w^T + in_b
     RC(dense_bwd_w(dqkv, h_in, dinw, M, 3 * Z, Z, scratch + X.pwin, red, st));
     HC(umlh_enc_launch_colsum_partial(dqkv, M, 3 * Z, d.chunk, p_inb, st));
@@ -246,6 +250,120 @@ int umlh_encoder_stack_backward(const umlh_enc_layer_t* cfg, int32_t n_layers, c
         g = out;
     }
     return UMLH_OK;
+}
+
+// ---- encoder plan: the stack on fixed buffers, replayed from HIP graphs ----
+struct umlh_enc_plan_s {
+    umlh_enc_layer_t cfg;
+    int n_layers, has_lengths, device;
+    const float** P;
+    float** G;
+    float* ws;
+    long long o_h0, o_lens, o_seed, o_hs, o_saved, o_scratch, o_dhout, o_dhtmp, o_dh0, o_grads, total;
+    hipStream_t cap;
+    hipGraphExec_t exec[2];
+    int calls[2];
+};
+
+static void plan_layout(const Dims& d, int n, umlh_enc_plan_s& p) {
+    long long o = 0;
+    auto take = [&](long long k) { long long r = o; o += ru64(k); return r; };
+    const long long mz = d.M * d.Z, Z = d.Z, F = d.F;
+    p.o_h0 = take(mz); p.o_lens = take(2LL * d.B); p.o_seed = take(2);
+    p.o_hs = take((long long)n * mz); p.o_saved = take((long long)n * saved_layout(d).total); p.o_scratch = take(scratch_layout(d).total);
+    p.o_dhout = take(mz); p.o_dhtmp = take(2 * mz); p.o_dh0 = take(mz);
+    p.o_grads = take((long long)n * (3 * Z * Z + 3 * Z + Z * Z + Z + F * Z + F + Z * F + Z + 4 * Z));
+    p.total = o;
+}
+
+uint64_t umlh_encoder_plan_floats(const umlh_enc_layer_t* cfg, int32_t n_layers) {
+    Dims d;
+    if (!dims_ok(cfg, d) || n_layers < 1) return 0;
+    umlh_enc_plan_s p;
+    plan_layout(d, n_layers, p);
+    return (uint64_t)p.total;
+}
+
+int umlh_encoder_plan_create(const umlh_enc_layer_t* cfg, int32_t n_layers, const float* const* P, int32_t has_lengths,
+                             float* workspace, umlh_enc_plan_t* out) {
+    Dims d;
+    if (!dims_ok(cfg, d) || n_layers < 1 || !P || !workspace || !out) return UMLH_E_INVALID;
+    umlh_enc_plan_s* p = new (std::nothrow) umlh_enc_plan_s();
+    if (!p) return UMLH_E_INVALID;
+    plan_layout(d, n_layers, *p);
+    p->cfg = *cfg;
+    p->cfg.seed = 0;
+    p->n_layers = n_layers; p->has_lengths = has_lengths; p->ws = workspace;
+    p->cfg.seed_device = reinterpret_cast<const uint64_t*>(workspace + p->o_seed);
+    p->P = new const float*[12 * n_layers];
+    p->G = new float*[12 * n_layers];
+    const long long Z = d.Z, F = d.F;
+    const long long sizes[12] = {3 * Z * Z, 3 * Z, Z * Z, Z, F * Z, F, Z * F, Z, Z, Z, Z, Z};
+    long long o = p->o_grads;
+    for (int i = 0; i < 12 * n_layers; ++i) { p->P[i] = P[i]; p->G[i] = workspace + o; o += sizes[i % 12]; }
+    p->exec[0] = p->exec[1] = nullptr;
+    p->calls[0] = p->calls[1] = 0;
+    if (hipGetDevice(&p->device) != hipSuccess || hipStreamCreateWithFlags(&p->cap, hipStreamNonBlocking) != hipSuccess) {
+        delete[] p->P; delete[] p->G; delete p;
+        return UMLH_E_HIP;
+    }
+    *out = p;
+    return UMLH_OK;
+}
+
+int umlh_encoder_plan_offsets(umlh_enc_plan_t p, uint64_t offsets[6]) {
+    if (!p || !offsets) return UMLH_E_INVALID;
+    Dims d;
+    dims_ok(&p->cfg, d);
+    offsets[0] = (uint64_t)p->o_h0; offsets[1] = (uint64_t)p->o_lens; offsets[2] = (uint64_t)(p->o_hs + (long long)(p->n_layers - 1) * d.M * d.Z);
+    offsets[3] = (uint64_t)p->o_dhout; offsets[4] = (uint64_t)p->o_dh0; offsets[5] = (uint64_t)p->o_grads;
+    return UMLH_OK;
+}
+
+static int plan_enqueue(umlh_enc_plan_t p, int dir, hipStream_t st) {
+    float* w = p->ws;
+    const int64_t* lens = p->has_lengths ? reinterpret_cast<const int64_t*>(w + p->o_lens) : nullptr;
+    if (dir == 0) return umlh_encoder_stack_forward(&p->cfg, p->n_layers, p->P, w + p->o_h0, lens, w + p->o_saved, w + p->o_scratch, w + p->o_hs, st);
+    return umlh_encoder_stack_backward(&p->cfg, p->n_layers, p->P, w + p->o_h0, lens, w + p->o_saved, w + p->o_hs, w + p->o_dhout,
+                                       w + p->o_scratch, p->G, w + p->o_dhtmp, w + p->o_dh0, st);
+}
+
+// call 0: plain launches (also sets the kernels' attributes, which a capture cannot); call 1: capture + instantiate; then replay
+static int plan_run(umlh_enc_plan_t p, int dir, hipStream_t st) {
+    static const bool no_graph = [] { const char* e = getenv("UMLH_ENC_GRAPH"); return e && atoi(e) == 0; }();
+    const int call = p->calls[dir]++;
+    if (call == 0 || no_graph) return plan_enqueue(p, dir, st);
+    if (!p->exec[dir]) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal) != hipSuccess) return UMLH_E_HIP;
+        const int rc = plan_enqueue(p, dir, p->cap);
+        const hipError_t e = hipStreamEndCapture(p->cap, &graph);
+        if (rc || e != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); return rc ? rc : UMLH_E_HIP; }
+        const hipError_t ei = hipGraphInstantiate(&p->exec[dir], graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ei != hipSuccess) { p->exec[dir] = nullptr; return UMLH_E_HIP; }
+    }
+    return hipGraphLaunch(p->exec[dir], st) == hipSuccess ? UMLH_OK : UMLH_E_HIP;
+}
+
+int umlh_encoder_plan_forward(umlh_enc_plan_t p, uint64_t seed, void* stream) {
+    if (!p) return UMLH_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    HC(umlh_enc_launch_set_u64(reinterpret_cast<unsigned long long*>(p->ws + p->o_seed), (unsigned long long)seed, st));
+    return plan_run(p, 0, st);
+}
+
+int umlh_encoder_plan_backward(umlh_enc_plan_t p, void* stream) {
+    if (!p) return UMLH_E_INVALID;
+    return plan_run(p, 1, (hipStream_t)stream);
+}
+
+void umlh_encoder_plan_destroy(umlh_enc_plan_t p) {
+    if (!p) return;
+    for (int i = 0; i < 2; ++i) if (p->exec[i]) hipGraphExecDestroy(p->exec[i]);
+    hipStreamDestroy(p->cap);
+    delete[] p->P; delete[] p->G;
+    delete p;
 }
 
 }  // extern "C"

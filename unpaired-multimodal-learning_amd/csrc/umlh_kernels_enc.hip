@@ -199,9 +199,10 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
                                                             int T, int B, int Z, int H, unsigned thresh, float inv_keep,
-                                                            unsigned long long seed, float* __restrict__ ctx,
-                                                            float* __restrict__ lse) {
+                                                            unsigned long long seed0, const unsigned long long* __restrict__ seed_ptr,
+                                                            float* __restrict__ ctx, float* __restrict__ lse) {
     extern __shared__ float sm[];
+    const unsigned long long seed = seed0 + (seed_ptr ? *seed_ptr : 0ull);
     const int dh = Z / H, rs = dh | 1, b = blockIdx.x / H, h = blockIdx.x % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* Qs = sm;
@@ -264,8 +265,10 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
                                                             const float* __restrict__ lse, const float* __restrict__ dctx,
                                                             int T, int B, int Z, int H, unsigned thresh, float inv_keep,
-                                                            unsigned long long seed, float* __restrict__ dqkv) {
+                                                            unsigned long long seed0, const unsigned long long* __restrict__ seed_ptr,
+                                                            float* __restrict__ dqkv) {
     extern __shared__ float sm[];
+    const unsigned long long seed = seed0 + (seed_ptr ? *seed_ptr : 0ull);
     const int dh = Z / H, rs = dh | 1, b = blockIdx.x / H, h = blockIdx.x % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* Qs = sm;
@@ -424,9 +427,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_fused_kernel(const flo
                                                                        const float* __restrict__ s, const float* __restrict__ gamma,
                                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                        int M, int N, float* __restrict__ ds, float* __restrict__ dsd,
-                                                                       unsigned thresh, float inv_keep, unsigned long long seed) {
+                                                                       unsigned thresh, float inv_keep, unsigned long long seed0,
+                                                                       const unsigned long long* __restrict__ seed_ptr) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
+    const unsigned long long seed = seed0 + (seed_ptr ? *seed_ptr : 0ull);
     const size_t o = (size_t)m * N;
     const float mu = mean[m], rs = rstd[m];
     const float* dyr = dy_out ? dy_out : dy;
@@ -499,15 +504,20 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(MultiReduceArgs a) {
 #pragma unroll 1
     while (t + 1 < a.count && (int)blockIdx.x >= a.d[t + 1].blk0) ++t;
     const ReduceDesc d = a.d[t];
+    const float scale = a.s_num ? a.s_mul * a.s_num[0] / a.s_den[0] : 1.f;
     const long long base = (long long)((int)blockIdx.x - d.blk0) * 1024 + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const long long i = base + 256 * q;
         if (i < d.n) {
-            d.dst[i] = slab_sum(d.src + i, d.stride, d.ns);
+            const float v = slab_sum(d.src + i, d.stride, d.ns);
+            d.dst[i] = a.s_num ? v * scale : v;
         }
     }
 }
+
+// *dst = v (the dropout seed word a captured launch sequence reads)
+__global__ void set_u64_kernel(unsigned long long* dst, unsigned long long v) { *dst = v; }
 
 inline unsigned drop_thresh(float p) { return p <= 0.f ? 0u : (unsigned)((double)p * 4294967296.0); }
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
@@ -580,10 +590,11 @@ int umlh_enc_launch_add_layernorm_fused(const float* x, int ns, long long stride
 
 int umlh_enc_launch_layernorm_bwd_rows_fused(const float* dy, int ns, long long stride, const float* add, float* dy_out, const float* s,
                                              const float* gamma, const float* mean, const float* rstd, int M, int N, float* ds,
-                                             float* dsd, float p, unsigned long long seed, hipStream_t st) {
+                                             float* dsd, float p, unsigned long long seed, const unsigned long long* seed_ptr,
+                                             hipStream_t st) {
     if (M <= 0) return 0;
     hipLaunchKernelGGL(layernorm_bwd_rows_fused_kernel, dim3((M + 3) / 4), dim3(256), 0, st, dy, ns, stride, add, dy_out, s, gamma, mean,
-                       rstd, M, N, ds, dsd, drop_thresh(p), p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+                       rstd, M, N, ds, dsd, drop_thresh(p), p > 0.f ? 1.f / (1.f - p) : 1.f, seed, seed_ptr);
     return (int)hipGetLastError();
 }
 
@@ -611,6 +622,11 @@ int umlh_enc_launch_multi_reduce(MultiReduceArgs* a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+int umlh_enc_launch_set_u64(unsigned long long* dst, unsigned long long v, hipStream_t st) {
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, st, dst, v);
+    return (int)hipGetLastError();
+}
+
 float umlh_enc_drop_inv_keep(float p) { return p > 0.f ? 1.f / (1.f - p) : 1.f; }
 unsigned umlh_enc_drop_thresh(float p) { return drop_thresh(p); }
 
@@ -632,7 +648,7 @@ int umlh_enc_launch_gather_rows(const float* x, const int64_t* idx, int n, int Z
 
 // returns hipErrorInvalidValue for shapes outside the kernel's envelope (T <= 128, head dim <= 64)
 int umlh_enc_launch_attention_fwd(const float* qkv, const int64_t* lengths, int T, int B, int Z, int H, float p,
-                                  unsigned long long seed, float* ctx, float* lse, hipStream_t st) {
+                                  unsigned long long seed, const unsigned long long* seed_ptr, float* ctx, float* lse, hipStream_t st) {
     if (T < 1 || T > ATM || H < 1 || Z % H != 0 || Z / H > ADH) return (int)hipErrorInvalidValue;
     const int rs = (Z / H) | 1;
     const size_t smem = sizeof(float) * (3 * (size_t)T * rs + AW * T);
@@ -644,12 +660,13 @@ int umlh_enc_launch_attention_fwd(const float* qkv, const int64_t* lengths, int 
         attr_done = true;
     }
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), smem, st, qkv, lengths, T, B, Z, H, drop_thresh(p),
-                       p > 0.f ? 1.f / (1.f - p) : 1.f, seed, ctx, lse);
+                       p > 0.f ? 1.f / (1.f - p) : 1.f, seed, seed_ptr, ctx, lse);
     return (int)hipGetLastError();
 }
 
 int umlh_enc_launch_attention_bwd(const float* qkv, const int64_t* lengths, const float* lse, const float* dctx, int T, int B,
-                                  int Z, int H, float p, unsigned long long seed, float* dqkv, hipStream_t st) {
+                                  int Z, int H, float p, unsigned long long seed, const unsigned long long* seed_ptr, float* dqkv,
+                                  hipStream_t st) {
     if (T < 1 || T > ATM || H < 1 || Z % H != 0 || Z / H > ADH) return (int)hipErrorInvalidValue;
     const int rs = (Z / H) | 1;
     const size_t smem = sizeof(float) * (4 * (size_t)T * rs + 2 * T + AW * 2 * T);
@@ -661,7 +678,7 @@ int umlh_enc_launch_attention_bwd(const float* qkv, const int64_t* lengths, cons
         attr_done = true;
     }
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), smem, st, qkv, lengths, lse, dctx, T, B, Z, H, drop_thresh(p),
-                       p > 0.f ? 1.f / (1.f - p) : 1.f, seed, dqkv);
+                       p > 0.f ? 1.f / (1.f - p) : 1.f, seed, seed_ptr, dqkv);
     return (int)hipGetLastError();
 }
 

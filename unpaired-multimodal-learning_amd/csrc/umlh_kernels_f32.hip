@@ -497,6 +497,154 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
 }
 
 // --------------------------------------------------------------------------- //
+// gemm_enc: the dense layers of the MultiBench encoder (no row gathers).  Same contract as gemm_f32 with a 64x64 tile,
+// but the K range is staged 64 reduction rows at a time and the NEXT 64 are already in flight while a chunk is multiplied:
+// these GEMMs are short (K = 40 .. 300, or a split-K range of 64-128 rows of a 1600 / 2048 long reduction) and tiny, so
+// their duration is the chain of dependent memory round trips, not MFMA time (20-32 MFMAs per chunk).  gemm_f32 walks K in
+// 16-row chunks with one barrier and one round trip each: 3 round trips for K = 40, 5 for an 80-row split.
+// --------------------------------------------------------------------------- //
+constexpr int EKC = 64;
+#ifdef UMLH_ABLATIONS
+__device__ unsigned long long* g_gemm_stamps = nullptr;   // analysis build: 16 cycle stamps of block (0,0,0) thread 0 (UMLH_DBG_GEMM_STAMPS = device address)
+#endif
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_enc(GemmArgs g) {
+    constexpr int LDA_ = TA == 0 ? 65 : 68, LDB_ = TB == 0 ? 65 : 68;   // transposing scalar stores want an odd stride, b128 stores 16-B rows
+    __shared__ __attribute__((aligned(16))) float As[EKC * LDA_];
+    __shared__ __attribute__((aligned(16))) float Bs[EKC * LDB_];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kb = blockIdx.z * g.k_chunk, ke = min(g.K, kb + g.k_chunk);
+    // 16-B pieces are loaded without branches (a guarded load per piece puts every load in its own basic block and the
+    // compiler waits for each before issuing the next: 8 dependent round trips per chunk): a piece is whole or absent --
+    // guaranteed when the contiguous extent is a multiple of 4 -- and an absent piece reads the operand's first 16 bytes
+    // and is zeroed by a select.  Operands that do not qualify (lda = 35, unaligned base) take 4 clamped scalar loads.
+    const bool vecA = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((TA == 0 ? g.K : g.M) % 4 == 0);
+    const bool vecB = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && ((TB == 0 ? g.K : g.N) % 4 == 0);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4v areg[4], breg[4];
+    const int pr = tid >> 4, pq = tid & 15;              // piece q of the thread: row/k-row pr + 16q, 16-B column pq
+    // piece at base[row*ld + col .. col+3]; row_ok: the row exists; lim: valid elements from col (<= 0: none)
+    auto piece = [&](const float* base, size_t row, int ld, int col, bool row_ok, int lim, bool vec) -> f32x4v {
+        f32x4v v;
+        if (vec) {
+            const bool ok = row_ok && lim >= 4;
+            v = *reinterpret_cast<const f32x4v*>(ok ? base + row * ld + col : base);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = row_ok && j < lim;
+                const float x = *(ok ? base + row * ld + col + j : base);
+                v[j] = ok ? x : 0.f;
+            }
+        }
+        return v;
+    };
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = pr + 16 * q;
+            if (TA == 0) areg[q] = piece(g.A, (size_t)(m0 + r), g.lda, k0 + 4 * pq, m0 + r < g.M, ke - (k0 + 4 * pq), vecA);       // A[m][k]
+            else         areg[q] = piece(g.A, (size_t)(k0 + r), g.lda, m0 + 4 * pq, k0 + r < ke, g.M - (m0 + 4 * pq), vecA);       // A[k][m]
+            if (TB == 0) breg[q] = piece(g.B, (size_t)(n0 + r), g.ldb, k0 + 4 * pq, n0 + r < g.N, ke - (k0 + 4 * pq), vecB);
+            else         breg[q] = piece(g.B, (size_t)(k0 + r), g.ldb, n0 + 4 * pq, k0 + r < ke, g.N - (n0 + 4 * pq), vecB);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = pr + 16 * q;
+            if (TA == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[(4 * pq + j) * LDA_ + r] = areg[q][j];
+            } else *reinterpret_cast<f32x4v*>(&As[r * LDA_ + 4 * pq]) = areg[q];
+            if (TB == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(4 * pq + j) * LDB_ + r] = breg[q][j];
+            } else *reinterpret_cast<f32x4v*>(&Bs[r * LDB_ + 4 * pq]) = breg[q];
+        }
+    };
+#ifdef UMLH_ABLATIONS
+    unsigned long long* stp = (g_gemm_stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) ? g_gemm_stamps : nullptr;
+    int sti = 0;
+#define GSTAMP() do { if (stp && sti < 15) stp[sti++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GSTAMP() do { } while (0)
+#endif
+    GSTAMP();
+    if (kb < ke) gload(kb);
+    GSTAMP();
+    for (int k0 = kb; k0 < ke; k0 += EKC) {
+        lstore();
+        GSTAMP();
+        __syncthreads();
+        GSTAMP();
+        if (k0 + EKC < ke) gload(k0 + EKC);
+        const int steps = (min(EKC, ke - k0) + 1) >> 1;  // rows past ke hold zeros
+        const float* ap = As + h * LDA_ + wm * 32 + l31;
+        const float* bp = Bs + h * LDB_ + wn * 32 + l31;
+#pragma unroll 4
+        for (int kk = 0; kk < steps; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * LDA_], bp[2 * kk * LDB_], acc, 0, 0, 0);
+        GSTAMP();
+        if (k0 + EKC < ke) __syncthreads();
+    }
+    float* out = g.out + (size_t)blockIdx.z * g.slab_stride;
+    const int n = n0 + wn * 32 + l31;
+    if (n < g.N) {
+        if (!(g.epi.on && gridDim.z == 1)) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 32 + acc_row(e, h);
+                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[e] * g.alpha;
+            }
+        } else {
+            // the operand loads of the tail are hoisted and batched (16 independent loads in flight); element by element
+            // behind `if (bias) .. if (gate) ..` they cost one memory round trip each (~9k of this kernel's ~20k cycles)
+            const Epilogue ep = g.epi;
+            const float bias = ep.bias ? ep.bias[n] : 0.f;
+            const unsigned long long seed = ep.seed + (ep.seed_ptr ? *ep.seed_ptr : 0ull);
+            float gt[16], ad[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { gt[e] = 1.f; ad[e] = 0.f; }
+            if (ep.gate) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * 32 + acc_row(e, h);
+                    gt[e] = ep.gate[m < g.M ? (size_t)m * g.ldo + n : (size_t)n];
+                }
+            }
+            if (ep.add) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * 32 + acc_row(e, h);
+                    ad[e] = ep.add[m < g.M ? (size_t)m * g.ldo + n : (size_t)n];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 32 + acc_row(e, h);
+                float v = acc[e] * g.alpha + bias;
+                if (ep.relu) v = fmaxf(v, 0.f);
+                v = gt[e] > 0.f ? v : 0.f;
+                if (ep.thresh) v = keep_elem(seed, (unsigned long long)((long long)m * g.ldo + n), ep.thresh) ? v * ep.inv_keep : 0.f;
+                v += ad[e];
+                if (m < g.M) out[(size_t)m * g.ldo + n] = v;
+            }
+        }
+    }
+    GSTAMP();
+#ifdef UMLH_ABLATIONS
+    if (stp) stp[15] = (unsigned long long)sti;
+#endif
+}
+
+// --------------------------------------------------------------------------- //
 // slab reduction (+ optimizer update)
 // --------------------------------------------------------------------------- //
 // MODE 0: grad_out = sum of slabs.  MODE 1: p,m,v updated from the sum (grad_out
@@ -851,6 +999,27 @@ int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStrea
     dim3 grid((g->N + t - 1) / t, (g->M + t - 1) / t, splits);
 #define GEMM_CASE(A_, B_, T_) if (ta == A_ && tb == B_ && tm == T_) { hipLaunchKernelGGL((gemm_f32<A_, B_, T_>), grid, dim3(256), 0, stream, *g); return (int)hipGetLastError(); }
     GEMM_CASE(0, 0, 1) GEMM_CASE(0, 0, 2) GEMM_CASE(0, 1, 1) GEMM_CASE(0, 1, 2) GEMM_CASE(1, 1, 1) GEMM_CASE(1, 1, 2)
+    return (int)hipErrorInvalidValue;
+}
+
+int umlh_f32_launch_gemm_enc(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream) {
+    if (g->M <= 0 || g->N <= 0) return 0;
+    if (g->a_rows || g->k_rows || g->B2 || g->nsplit1 || g->alpha_ptr) return (int)hipErrorInvalidValue;
+    dim3 grid((g->N + 63) / 64, (g->M + 63) / 64, splits);
+#ifdef UMLH_ABLATIONS
+    {
+        const char* e = getenv("UMLH_DBG_GEMM_STAMPS");
+        static int last_sel = -2;
+        const char* sel = getenv("UMLH_DBG_GEMM_CALL");            // index of the gemm_enc launch to stamp
+        static int call = 0;
+        unsigned long long* ptr = (e && sel && atoi(sel) == call) ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
+        (void)last_sel;
+        ++call;
+        hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gemm_stamps), &ptr, sizeof(ptr), 0, hipMemcpyHostToDevice, stream);
+    }
+#endif
+#define GEMM_ENC_CASE(A_, B_) if (ta == A_ && tb == B_) { hipLaunchKernelGGL((gemm_enc<A_, B_>), grid, dim3(256), 0, stream, *g); return (int)hipGetLastError(); }
+    GEMM_ENC_CASE(0, 0) GEMM_ENC_CASE(0, 1) GEMM_ENC_CASE(1, 1)
     return (int)hipErrorInvalidValue;
 }
 

@@ -127,8 +127,9 @@ int umlh_seq_launch_fwd(const float* z, const float* w, const float* b, const fl
     return (int)hipGetLastError();
 }
 int umlh_seq_launch_bwd(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out, int B,
-                        int T, int Z, int D, float* dz, float* dw, float* db, hipStream_t st) {
+                        int T, int Z, int D, float* dz, float* dw, float* db, int with_params, hipStream_t st) {
     hipLaunchKernelGGL(seq_mse_bwd_dz_kernel, dim3(B * T), dim3(128), sizeof(float) * D, st, dres, w, loss_cnt, grad_out, Z, D, dz);
+    if (!with_params) return (int)hipGetLastError();     // dW / db by the caller (split-K slabs + row-chunk partials)
     hipLaunchKernelGGL(seq_mse_bwd_db_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, dres, loss_cnt, grad_out, B * T, D, db);
     // dW[d][k] = s * sum_r dres[r][d] z[r][k]: the transposed-A GEMM of the fp32 MFMA kernel, then the device-side scale
     GemmArgs g;

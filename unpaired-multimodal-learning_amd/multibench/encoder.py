@@ -46,8 +46,9 @@ def _splits(m, n, k):
     return max(1, min(32, k // 64, -(-768 // tiles)))
 
 
-def gemm(a, b, m, n, k, lda, ldb, ta, tb, a_rows=None, k_rows=None, alpha=1.0):
-    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+def gemm(a, b, m, n, k, lda, ldb, ta, tb, a_rows=None, k_rows=None, alpha=1.0, out=None):
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     sp = _splits(m, n, k)
     slabs = torch.empty(sp, m, n, dtype=torch.float32, device=a.device) if sp > 1 else None
     check(umlh.load_library().umlh_gemm_f32(_p(a), _p(b), _p(out), m, n, k, lda, ldb, n, ta, tb, _p(a_rows), _p(k_rows),
@@ -55,10 +56,10 @@ def gemm(a, b, m, n, k, lda, ldb, ta, tb, a_rows=None, k_rows=None, alpha=1.0):
     return out
 
 
-def linear_forward(x, w, b, relu=False, a_rows=None, rows=None):
+def linear_forward(x, w, b, relu=False, a_rows=None, rows=None, out=None):
     """y = act(x w^T + b); x [M,K] (rows optionally gathered by a_rows -> `rows` output rows), w [N,K]."""
     m = x.shape[0] if rows is None else rows
-    y = gemm(x, w, m, w.shape[0], w.shape[1], x.shape[1], w.shape[1], 0, 0, a_rows=a_rows)
+    y = gemm(x, w, m, w.shape[0], w.shape[1], x.shape[1], w.shape[1], 0, 0, a_rows=a_rows, out=out)
     if b is not None or relu:
         check(umlh.load_library().umlh_bias_act(_p(y), _p(b), m, w.shape[0], int(relu), _st(x.device)), "umlh_bias_act")
     return y
@@ -116,7 +117,62 @@ N_LAYER_PARAMS = 12   # in_w, in_b, out_w, out_b, w1, b1, w2, b2, g1, be1, g2, b
 
 def _layer_cfg(T, B, Z, H, dff, p, eps, seed):
     from umlh._lib import EncLayer
-    return EncLayer(int(T), int(B), int(Z), int(H), int(dff), float(p), float(eps), int(seed) & (2 ** 64 - 1))
+    return EncLayer(int(T), int(B), int(Z), int(H), int(dff), float(p), float(eps), int(seed) & (2 ** 64 - 1), None)
+
+
+class _Plan:
+    """umlh_encoder_plan_*: the layer stack bound to fixed buffers (one torch allocation) whose launch sequences replay from
+    HIP graphs.  A plan serves one forward/backward pair at a time: EncoderFn leases it for the lifetime of the autograd
+    node (the saved activations live in the plan) and the pool hands out / creates another one meanwhile."""
+
+    def __init__(self, lc, n_layers, lp, has_lens, dev):
+        lib = umlh.load_library()
+        n = int(lib.umlh_encoder_plan_floats(C.byref(lc), n_layers))
+        if n == 0:
+            raise umlh.UmlhError(f"encoder layer shape outside the kernels' envelope: T={lc.T} Z={lc.Z} H={lc.H}")
+        self.ws = torch.empty(n, dtype=torch.float32, device=dev)
+        self.params = lp                                   # keeps the tensors whose addresses the graphs hold alive
+        h = C.c_void_p()
+        check(lib.umlh_encoder_plan_create(C.byref(lc), n_layers, _ptr_array(lp), int(has_lens), _p(self.ws), C.byref(h)), "umlh_encoder_plan_create")
+        self.handle = h
+        offs = (C.c_uint64 * 6)()
+        check(lib.umlh_encoder_plan_offsets(h, offs), "umlh_encoder_plan_offsets")
+        M, Z, B = lc.T * lc.B, lc.Z, lc.B
+        view = lambda o, k: self.ws[int(o):int(o) + k]
+        self.h0, self.h_last = view(offs[0], M * Z).view(M, Z), view(offs[2], M * Z).view(M, Z)
+        self.lens = view(offs[1], 2 * B).view(torch.int64) if has_lens else None
+        self.dh_out, self.dh0 = view(offs[3], M * Z).view(M, Z), view(offs[4], M * Z).view(M, Z)
+        self.grads = view(offs[5], sum(t.numel() for t in lp))
+        self.busy = False
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            umlh.load_library().umlh_encoder_plan_destroy(h)
+
+
+class _Lease:
+    def __init__(self, plan):
+        self.plan = plan
+        plan.busy = True
+
+    def __del__(self):
+        self.plan.busy = False
+
+
+_PLANS = {}
+_PLAN_POOL_MAX = 8          # plans kept per configuration (each holds the stack's saved activations: ~0.1 GB at MOSEI sizes)
+
+
+def _lease_plan(key, make):
+    pool = _PLANS.setdefault(key, [])
+    for pl in pool:
+        if not pl.busy:
+            return _Lease(pl)
+    pl = make()
+    if len(pool) < _PLAN_POOL_MAX:
+        pool.append(pl)
+    return _Lease(pl)
 
 
 def _ptr_array(tensors):
@@ -141,34 +197,30 @@ class EncoderFn(torch.autograd.Function):
         rows_tb = (ar_b.unsqueeze(0) * T + ar_t.unsqueeze(1)).reshape(-1).contiguous()      # token row m=(t,b) -> source row b*T+t
         rows_bt = (ar_t.unsqueeze(0) * B + ar_b.unsqueeze(1)).reshape(-1).contiguous()      # source row (b,t) -> token row t*B+b
         M = T * B
-        if conv_w is not None:
-            cw = _f32(conv_w).reshape(conv_w.shape[0], -1)
-            h = linear_forward(x2d, cw, None, a_rows=rows_tb, rows=M)                        # [M, Z]
-        else:
-            cw = None
-            h = torch.empty(M, F, dtype=torch.float32, device=dev)
-            check(lib.umlh_gather_rows(_p(x2d), _p(rows_tb), M, F, _p(h), 0, st), "umlh_gather_rows")
-        Z = h.shape[1]
-        if pos is not None:
-            check(lib.umlh_add_positions(_p(h), _p(_f32(pos)), T, B, Z, st), "umlh_add_positions")
         n_layers = len(layer_params) // N_LAYER_PARAMS
         lp = [_f32(t) for t in layer_params]
-        # one C call for the layer stack (umlh_encoder_stack_forward enqueues every layer's launch sequence); the activations
-        # the backward needs live in one caller-owned buffer
+        Z = conv_w.shape[0] if conv_w is not None else F
         dff = lp[4].shape[0] if n_layers else 0
-        saved = hs = None
-        h0 = h
+        lease = plan = None
         if n_layers:
-            lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed)
-            n_saved, n_scr = int(lib.umlh_encoder_layer_saved_floats(C.byref(lc))), int(lib.umlh_encoder_layer_scratch_floats(C.byref(lc)))
-            if n_saved == 0:
-                raise umlh.UmlhError(f"encoder layer shape outside the kernels' envelope: T={T} Z={Z} H={H}")
-            scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
-            saved = torch.empty(n_layers * n_saved, dtype=torch.float32, device=dev)
-            hs = torch.empty(n_layers, M, Z, dtype=torch.float32, device=dev)
-            check(lib.umlh_encoder_stack_forward(C.byref(lc), n_layers, _ptr_array(lp), _p(h0), _p(lens), _p(saved), _p(scratch), _p(hs), st),
-                  "umlh_encoder_stack_forward")
-            h = hs[n_layers - 1]
+            # the layer stack runs on a leased plan: fixed buffers, one HIP-graph launch per direction
+            key = (dev.index, T, B, Z, H, dff, float(p), float(eps), n_layers, lens is not None, tuple(t.data_ptr() for t in lp))
+            lease = _lease_plan(key, lambda: _Plan(_layer_cfg(T, B, Z, H, dff, p, eps, 0), n_layers, lp, lens is not None, dev))
+            plan = lease.plan
+        if conv_w is not None:
+            cw = _f32(conv_w).reshape(conv_w.shape[0], -1)
+            h = linear_forward(x2d, cw, None, a_rows=rows_tb, rows=M, out=None if plan is None else plan.h0)     # [M, Z]
+        else:
+            cw = None
+            h = torch.empty(M, F, dtype=torch.float32, device=dev) if plan is None else plan.h0
+            check(lib.umlh_gather_rows(_p(x2d), _p(rows_tb), M, F, _p(h), 0, st), "umlh_gather_rows")
+        if pos is not None:
+            check(lib.umlh_add_positions(_p(h), _p(_f32(pos)), T, B, Z, st), "umlh_add_positions")
+        if plan is not None:
+            if lens is not None:
+                plan.lens.copy_(lens)
+            check(lib.umlh_encoder_plan_forward(plan.handle, C.c_uint64(int(seed) & (2 ** 64 - 1)), st), "umlh_encoder_plan_forward")
+            h = plan.h_last
         mode = cfg["out_mode"]
         if mode == "all":
             idx, n_out = rows_bt, M
@@ -179,7 +231,7 @@ class EncoderFn(torch.autograd.Function):
         out = torch.empty(n_out, Z, dtype=torch.float32, device=dev)
         check(lib.umlh_gather_rows(_p(h), _p(idx), n_out, Z, _p(out), 0, st), "umlh_gather_rows")
         ctx.cfg, ctx.dims = cfg, (B, T, F, Z, M, n_layers)
-        ctx.aux = (x2d, lens, rows_tb, rows_bt, idx, cw, pos is not None, lp, saved, h0, hs, dff)
+        ctx.aux = (x2d, rows_tb, rows_bt, idx, cw, pos is not None, lp, lease)
         ctx.need_dx = x.requires_grad
         return out.reshape(B, T, Z) if mode == "all" else out
 
@@ -188,26 +240,21 @@ class EncoderFn(torch.autograd.Function):
         lib = umlh.load_library()
         cfg = ctx.cfg
         B, T, F, Z, M, n_layers = ctx.dims
-        x2d, lens, rows_tb, rows_bt, idx, cw, has_pos, lp, saved, h0, hs, dff = ctx.aux
-        H, p, eps, seed = cfg["H"], cfg["p"], cfg["eps"], cfg["seed"]
+        x2d, rows_tb, rows_bt, idx, cw, has_pos, lp, lease = ctx.aux
         dev = g_out.device
         st = _st(dev)
         g = _f32(g_out).reshape(-1, Z)
-        dh = torch.zeros(M, Z, dtype=torch.float32, device=dev)
+        plan = None if lease is None else lease.plan
+        dh = torch.zeros(M, Z, dtype=torch.float32, device=dev) if plan is None else plan.dh_out.zero_()
         check(lib.umlh_gather_rows(_p(g), _p(idx), g.shape[0], Z, _p(dh), 1, st), "umlh_gather_rows(scatter)")
-        grads = [None] * (n_layers * N_LAYER_PARAMS)
-        if n_layers:
-            lc = _layer_cfg(T, B, Z, H, dff, p, eps, seed)
-            scratch = torch.empty(int(lib.umlh_encoder_layer_scratch_floats(C.byref(lc))), dtype=torch.float32, device=dev)
-            flat = torch.empty(sum(t.numel() for t in lp), dtype=torch.float32, device=dev)       # one allocation for every gradient
-            grads, o = [], 0
+        grads = []
+        if plan is not None:
+            check(lib.umlh_encoder_plan_backward(plan.handle, st), "umlh_encoder_plan_backward")
+            flat, o = plan.grads.clone(), 0                 # the plan's buffers are rewritten by its next backward
             for t in lp:
                 grads.append(flat[o:o + t.numel()].view(t.shape))
                 o += t.numel()
-            tmp = torch.empty(3, M, Z, dtype=torch.float32, device=dev)                         # 2 ping-pong buffers + the result
-            check(lib.umlh_encoder_stack_backward(C.byref(lc), n_layers, _ptr_array(lp), _p(h0), _p(lens), _p(saved), _p(hs), _p(dh),
-                                                  _p(scratch), _ptr_array(grads), _p(tmp), _p(tmp[2]), st), "umlh_encoder_stack_backward")
-            dh = tmp[2]
+            dh = plan.dh0
         dpos = None
         if has_pos:
             dpos = torch.empty(T, Z, dtype=torch.float32, device=dev)

@@ -150,7 +150,8 @@ class _DecoderNextStepMSE(torch.autograd.Function):
         db = torch.empty(D, dtype=torch.float32, device=z.device)
         st = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
         p = lambda t: C.c_void_p(t.data_ptr())
-        umlh._lib.check(lib.umlh_seq_mse_backward(p(z), p(w), p(dres), p(loss_cnt), p(g), B, T, Z, D, p(dz), p(dw), p(db), st),
+        scratch = torch.empty(int(lib.umlh_seq_mse_backward_scratch_floats(B, T, Z, D)), dtype=torch.float32, device=z.device)
+        umlh._lib.check(lib.umlh_seq_mse_backward(p(z), p(w), p(dres), p(loss_cnt), p(g), B, T, Z, D, p(dz), p(dw), p(db), p(scratch), st),
                         "umlh_seq_mse_backward")
         return dz, dw, db, None, None
 

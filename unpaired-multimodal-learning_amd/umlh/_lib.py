@@ -26,13 +26,15 @@ EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_w
            "umlh_apply_update", "umlh_eval_batch", "umlh_eval_rows", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
            "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_comm_unique_id", "umlh_comm_init_rank",
-           "umlh_set_comm", "umlh_set_allreduce", "umlh_seq_mse_forward", "umlh_seq_mse_backward",
+           "umlh_set_comm", "umlh_set_allreduce", "umlh_seq_mse_forward", "umlh_seq_mse_backward", "umlh_seq_mse_backward_scratch_floats",
            "umlh_random_permutation", "umlh_debug_buffer",
            "umlh_gemm_f32", "umlh_add_inplace", "umlh_bias_act", "umlh_relu_backward", "umlh_dropout", "umlh_colsum",
            "umlh_add_layernorm_forward", "umlh_layernorm_backward", "umlh_add_positions", "umlh_positions_backward",
            "umlh_gather_rows", "umlh_attention_forward", "umlh_attention_backward", "umlh_optimizer_step_multi",
            "umlh_encoder_layer_saved_floats", "umlh_encoder_layer_scratch_floats", "umlh_encoder_layer_forward",
-           "umlh_encoder_layer_backward", "umlh_encoder_stack_forward", "umlh_encoder_stack_backward"]
+           "umlh_encoder_layer_backward", "umlh_encoder_stack_forward", "umlh_encoder_stack_backward",
+           "umlh_encoder_plan_floats", "umlh_encoder_plan_create", "umlh_encoder_plan_offsets", "umlh_encoder_plan_forward",
+           "umlh_encoder_plan_backward", "umlh_encoder_plan_destroy"]
 
 
 class UmlhError(RuntimeError):
@@ -75,7 +77,7 @@ class GroupItem(C.Structure):
 
 class EncLayer(C.Structure):
     _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("Z", C.c_int32), ("H", C.c_int32), ("d_ff", C.c_int32),
-                ("p", C.c_float), ("eps", C.c_float), ("seed", C.c_uint64)]
+                ("p", C.c_float), ("eps", C.c_float), ("seed", C.c_uint64), ("seed_device", C.c_void_p)]
 
 
 class Hyper(C.Structure):
@@ -168,6 +170,14 @@ def load_library():
     lib.umlh_encoder_layer_backward.argtypes = [C.POINTER(EncLayer), pv, vp, vp, vp, vp, vp, pv, vp, vp]
     lib.umlh_encoder_stack_forward.argtypes = [C.POINTER(EncLayer), i32, pv, vp, vp, vp, vp, vp, vp]
     lib.umlh_encoder_stack_backward.argtypes = [C.POINTER(EncLayer), i32, pv, vp, vp, vp, vp, vp, vp, pv, vp, vp, vp]
+    lib.umlh_encoder_plan_floats.restype = u64
+    lib.umlh_encoder_plan_floats.argtypes = [C.POINTER(EncLayer), i32]
+    lib.umlh_encoder_plan_create.argtypes = [C.POINTER(EncLayer), i32, pv, i32, vp, C.POINTER(vp)]
+    lib.umlh_encoder_plan_offsets.argtypes = [vp, C.POINTER(u64)]
+    lib.umlh_encoder_plan_forward.argtypes = [vp, u64, vp]
+    lib.umlh_encoder_plan_backward.argtypes = [vp, vp]
+    lib.umlh_encoder_plan_destroy.restype = None
+    lib.umlh_encoder_plan_destroy.argtypes = [vp]
     lib.umlh_train_steps.argtypes = [vp, C.POINTER(Stream), C.POINTER(Stream), i32, C.POINTER(C.c_double), i64,
                                      C.c_float, C.c_float, vp, vp]
     lib.umlh_train_steps_grouped.argtypes = [C.POINTER(GroupItem), i32, i32, vp]
@@ -178,7 +188,9 @@ def load_library():
     lib.umlh_set_comm.argtypes = [vp, vp, i32]
     lib.umlh_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32]
     lib.umlh_seq_mse_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
-    lib.umlh_seq_mse_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.umlh_seq_mse_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.umlh_seq_mse_backward_scratch_floats.restype = u64
+    lib.umlh_seq_mse_backward_scratch_floats.argtypes = [i32, i32, i32, i32]
     lib.umlh_random_permutation.argtypes = [i64, u64, vp, vp]
     lib.umlh_debug_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.umlh_profile_enable.argtypes = [vp, C.c_int]
