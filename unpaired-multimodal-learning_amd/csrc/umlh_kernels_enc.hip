@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // --------------------------------------------------------------------------- //
 constexpr int ADH = 64;    // max head dim
 constexpr int ATM = 128;   // max sequence length
-constexpr int AW = 4;      // waves per workgroup
+constexpr int AW = 8;      // waves per workgroup
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -197,7 +197,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
+__global__ __launch_bounds__(64 * AW) void attention_fwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
                                                             int T, int B, int Z, int H, unsigned thresh, float inv_keep,
                                                             unsigned long long seed0, const unsigned long long* __restrict__ seed_ptr,
                                                             float* __restrict__ ctx, float* __restrict__ lse) {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
     int dhp = 1;
     while (dhp < dh) dhp <<= 1;                        // the P.V product spreads the keys over G = 64/dhp lane groups
     const int G = 64 / dhp, dl = lane & (dhp - 1), grp = lane / dhp;
-    for (int i = threadIdx.x; i < T * dh; i += 256) {
+    for (int i = threadIdx.x; i < T * dh; i += 64 * AW) {
         int j = i / dh, d = i % dh;
         const float* row = qkv + ((size_t)j * B + b) * 3 * Z + h * dh + d;
         Qs[j * rs + d] = row[0] * scale;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 
 // backward: p_tj = exp(s_tj - lse_t), dP_tj = (dO_t . v_j) * mask/(1-p), D_t = sum_j p_tj dP_tj,
 // dS_tj = p_tj (dP_tj - D_t) * scale;  dq_t = sum_j dS_tj k_j, dk_j = sum_t dS_tj q_t, dv_j = sum_t pdrop_tj dO_t
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
+__global__ __launch_bounds__(64 * AW) void attention_bwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ lengths,
                                                             const float* __restrict__ lse, const float* __restrict__ dctx,
                                                             int T, int B, int Z, int H, unsigned thresh, float inv_keep,
                                                             unsigned long long seed0, const unsigned long long* __restrict__ seed_ptr,
@@ -279,14 +279,14 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     float* Ls = Ds + T;                                // [T] lse_t
     float* S1 = Ls + T + wave * 2 * T;                 // per wave: [T] dS, [T] dropped probabilities
     float* S2 = S1 + T;
-    for (int i = threadIdx.x; i < T * dh; i += 256) {
+    for (int i = threadIdx.x; i < T * dh; i += 64 * AW) {
         int j = i / dh, d = i % dh;
         const float* row = qkv + ((size_t)j * B + b) * 3 * Z + h * dh + d;
         Qs[j * rs + d] = row[0]; Ks[j * rs + d] = row[Z]; Vs[j * rs + d] = row[2 * Z];
         Gs[j * rs + d] = dctx[((size_t)j * B + b) * Z + h * dh + d];
     }
     const unsigned long long hb = ((unsigned long long)b * H + h) * T;
-    for (int i = threadIdx.x; i < T; i += 256) Ls[i] = lse[hb + i];
+    for (int i = threadIdx.x; i < T; i += 64 * AW) Ls[i] = lse[hb + i];
     __syncthreads();
     const int len = lengths ? (int)lengths[b] : T;
     const float scale = rsqrtf((float)dh);
@@ -659,7 +659,7 @@ int umlh_enc_launch_attention_fwd(const float* qkv, const int64_t* lengths, int 
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), smem, st, qkv, lengths, T, B, Z, H, drop_thresh(p),
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(64 * AW), smem, st, qkv, lengths, T, B, Z, H, drop_thresh(p),
                        p > 0.f ? 1.f / (1.f - p) : 1.f, seed, seed_ptr, ctx, lse);
     return (int)hipGetLastError();
 }
@@ -677,7 +677,7 @@ int umlh_enc_launch_attention_bwd(const float* qkv, const int64_t* lengths, cons
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), smem, st, qkv, lengths, lse, dctx, T, B, Z, H, drop_thresh(p),
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(64 * AW), smem, st, qkv, lengths, lse, dctx, T, B, Z, H, drop_thresh(p),
                        p > 0.f ? 1.f / (1.f - p) : 1.f, seed, seed_ptr, dqkv);
     return (int)hipGetLastError();
 }
