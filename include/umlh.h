@@ -284,6 +284,17 @@ int  umlh_seq_mse_backward(const float* z, const float* w, const float* dres, co
                            void* stream);
 uint64_t umlh_seq_mse_backward_scratch_floats(int32_t B, int32_t T, int32_t Z, int32_t D);
 
+/* SequenceInfoNCELoss (MultiBench/models.py:145-175), the contrastive alternative to the next-step MSE: over the n valid
+ * (batch, time) rows, logits = normalize(pred) normalize(target)^T / temperature, labels = the diagonal, loss = mean CE.
+ * pred / target [n, D] dense fp32 rows (the caller selects the valid rows, as the reference's boolean indexing does).
+ * Forward leaves: pred_hat, target_hat [n, D] (unit rows), pred_norm [n], probs [n, n] = softmax(logits) - I, row_loss [n],
+ * loss (device scalar).  Backward: grad_out device scalar; dhat [n, D] scratch; dpred [n, D] = d loss / d pred * grad_out.
+ * (No gradient flows to the targets: they are the model's inputs.) */
+int  umlh_infonce_forward(const float* pred, const float* target, int32_t n, int32_t D, float temperature, float* pred_hat,
+                          float* target_hat, float* pred_norm, float* probs, float* row_loss, float* loss, void* stream);
+int  umlh_infonce_backward(const float* pred_hat, const float* target_hat, const float* pred_norm, const float* probs,
+                           const float* grad_out, int32_t n, int32_t D, float temperature, float* dhat, float* dpred, void* stream);
+
 /* ---- MultiBench shared encoder (MultiBench/models.py:39-127: Conv1d k=1 -> positions -> 5 x post-norm
  * nn.TransformerEncoderLayer(z, nhead, dim_feedforward=2048, relu, dropout) under a causal + key-padding
  * mask), forward and backward, fp32.  Token rows are m = t*B + b of a [T,B,*] activation (torch's

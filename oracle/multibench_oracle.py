@@ -46,3 +46,25 @@ def alternation_alphas(epoch: int, step_k: int, train_mode: str, alpha_x: float,
     epoch <= step_k (train only on y first)."""
     ax = 0.0 if (epoch <= step_k and train_mode == "xy") else alpha_x
     return ax, alpha_y
+
+
+def infonce_loss(pred: np.ndarray, target: np.ndarray, mask=None, temperature: float = 0.07):
+    """models.SequenceInfoNCELoss.forward (MultiBench/models.py:145-175): the valid (batch, time) rows of predictions and
+    targets are L2-normalised (F.normalize: x / max(|x|, 1e-12)), logits = p t^T / temperature, labels = arange(n), loss =
+    mean cross-entropy.  Returns (loss, d loss / d predictions) with the gradient scattered back to the [B, T, D] layout."""
+    sel = np.ones(pred.shape[:2], bool) if mask is None else np.asarray(mask).astype(bool)
+    p, t = pred[sel].astype(np.float64), target[sel].astype(np.float64)
+    n = p.shape[0]
+    pn = np.maximum(np.linalg.norm(p, axis=1, keepdims=True), 1e-12)
+    tn = np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-12)
+    ph, th = p / pn, t / tn
+    logits = ph @ th.T / temperature
+    mx = logits.max(1, keepdims=True)
+    lse = mx[:, 0] + np.log(np.exp(logits - mx).sum(1))
+    loss = float((lse - np.diag(logits)).mean())
+    dl = (np.exp(logits - lse[:, None]) - np.eye(n)) / n
+    dph = dl @ th / temperature
+    dp = (dph - ph * (ph * dph).sum(1, keepdims=True)) / pn
+    out = np.zeros(pred.shape, np.float64)
+    out[sel] = dp
+    return loss, out

@@ -39,3 +39,15 @@ def test_alternation_schedule():
     from multibench.train import alternation_alphas
     for e, k, mode in [(0, 10, "xy"), (11, 10, "xy"), (3, 2, "y"), (0, -1, "xy")]:
         assert tuple(alternation_alphas(e, k, mode, 0.7, 1.3)) == MO.alternation_alphas(e, k, mode, 0.7, 1.3)
+
+
+def test_infonce_oracle_matches_reference_golden():
+    """oracle.multibench_oracle.infonce_loss (restating MultiBench/models.py:145-175) against the reference's own
+    SequenceInfoNCELoss outputs and autograd gradient (tests/golden/infonce.npz, oracle/make_golden_infonce.py)."""
+    from conftest import load_golden
+    g = load_golden("infonce")
+    for tag in ("small", "masked", "wide", "one_row_seqs"):
+        mask = g[f"{tag}::mask"] if int(g[f"{tag}::masked"]) else None
+        loss, dp = MO.infonce_loss(g[f"{tag}::pred"], g[f"{tag}::tgt"], mask, float(g[f"{tag}::temperature"]))
+        assert abs(loss - float(g[f"{tag}::loss"])) < 2e-5, tag
+        np.testing.assert_allclose(dp, g[f"{tag}::dpred"], atol=2e-6, rtol=2e-4, err_msg=tag)

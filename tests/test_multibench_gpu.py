@@ -126,3 +126,62 @@ def test_get_embedding_is_time_mean_of_encoder_outputs():
         ry = m.encoder(m.yproj_in(y)).mean(dim=1)
     np.testing.assert_allclose(ex.cpu().numpy(), rx.cpu().numpy(), atol=1e-6, rtol=1e-5)
     np.testing.assert_allclose(ey.cpu().numpy(), ry.cpu().numpy(), atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["small", "masked", "wide", "one_row_seqs"])
+def test_infonce_hip_op_matches_reference_golden(tag):
+    """SequenceInfoNCELoss on the HIP op (umlh_infonce_forward / _backward) against the reference's loss and autograd
+    gradient (MultiBench/models.py:145-175; tests/golden/infonce.npz)."""
+    from multibench.models import SequenceInfoNCELoss
+    g = load_golden("infonce")
+    pred = torch.as_tensor(g[f"{tag}::pred"]).to(DEV).requires_grad_(True)
+    tgt = torch.as_tensor(g[f"{tag}::tgt"]).to(DEV)
+    mask = torch.as_tensor(g[f"{tag}::mask"]).to(DEV) if int(g[f"{tag}::masked"]) else None
+    loss = SequenceInfoNCELoss(float(g[f"{tag}::temperature"]))(pred, tgt, mask=mask)
+    loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}::loss"])) < 1e-4
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), g[f"{tag}::dpred"], atol=2e-6, rtol=1e-3)
+
+
+def test_infonce_hip_op_at_mosei_size_against_oracle():
+    """n = 32 x 49 valid rows of width 300 (the MOSEI text modality): loss and gradient against the pinned oracle."""
+    from multibench.models import SequenceInfoNCELoss
+    rng = np.random.default_rng(5)
+    B, Tn, D = 32, 49, 300
+    pred = rng.standard_normal((B, Tn, D)).astype(np.float32)
+    tgt = (0.5 * pred + rng.standard_normal((B, Tn, D))).astype(np.float32)
+    lens = rng.integers(1, Tn + 1, B)
+    lens[0] = Tn
+    mask = np.arange(Tn)[None, :] < lens[:, None]
+    ref_loss, ref_dp = MO.infonce_loss(pred, tgt, mask, 0.07)
+    tp = torch.as_tensor(pred).to(DEV).requires_grad_(True)
+    loss = SequenceInfoNCELoss(0.07)(tp, torch.as_tensor(tgt).to(DEV), mask=torch.as_tensor(mask).to(DEV))
+    (3.0 * loss).backward()
+    assert abs(float(loss) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    np.testing.assert_allclose(tp.grad.cpu().numpy(), 3.0 * ref_dp, atol=1e-6 * np.abs(ref_dp).max() * 50, rtol=2e-3)
+
+
+def test_uml_step_with_infonce_critic_matches_reference():
+    """UML(infoNCE_loss=True): loss_x (next-step MSE), loss_y (InfoNCE) and parameter gradients against the reference model."""
+    from multibench.models import Linear, Transformer, UML
+    g = load_golden("infonce")
+    z, dx, dy, B, Tn = (int(v) for v in g["model::cfg"])
+    m = UML(Linear(dx, z), Linear(dy, z), Transformer(z, z, nhead=5, num_layers=2, conv1d=True, out_last=False, pos_embd=True,
+                                                       pos_learnable=False, max_len=128),
+            [Linear(z, dx), Linear(z, dy)], modality="xy", infoNCE_loss=True)
+    sd = {k[len("model::sd::"):]: torch.as_tensor(g[k]) for k in g.files if k.startswith("model::sd::")}
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    T = lambda a: torch.as_tensor(a).to(DEV)
+    out = m(T(g["model::x"]), T(g["model::y"]), T(g["model::lx"]), T(g["model::ly"]))
+    assert abs(float(out["loss_x"]) - float(g["model::loss_x"])) < 1e-4
+    assert abs(float(out["loss_y"]) - float(g["model::loss_y"])) < 2e-4
+    (out["loss_x"] + out["loss_y"]).backward()
+    n = 0
+    for k, p in m.named_parameters():
+        if "model::g::" + k in g.files:
+            ref = g["model::g::" + k]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=3e-4 * max(np.abs(ref).max(), 1e-3), rtol=3e-3, err_msg=k)
+            n += 1
+    assert n >= 5

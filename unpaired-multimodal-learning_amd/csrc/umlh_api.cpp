@@ -539,6 +539,10 @@ int umlh_seq_launch_fwd(const float* z, const float* w, const float* b, const fl
                         int Z, int D, float* recon, float* dres, float* row_partial, float* loss_cnt, hipStream_t st);
 int umlh_seq_launch_bwd(const float* z, const float* w, const float* dres, const float* loss_cnt, const float* grad_out, int B,
                         int T, int Z, int D, float* dz, float* dw, float* db, int with_params, hipStream_t st);
+int umlh_seq_launch_l2norm(const float* x, int n, int D, float* y, float* norm, hipStream_t st);
+int umlh_seq_launch_nce_rows(float* dots, int n, float inv_temp, float* row_loss, float* loss, hipStream_t st);
+int umlh_seq_launch_l2norm_bwd(const float* dy, const float* y, const float* norm, const float* grad_out, float scale, int n, int D,
+                               float* dx, hipStream_t st);
 }
 
 int umlh_seq_mse_forward(const float* z, const float* w, const float* bias, const float* x, const int64_t* lengths, int32_t B,
@@ -593,6 +597,35 @@ int umlh_seq_mse_backward(const float* z, const float* w, const float* dres, con
     red.count = 2;
     red.s_num = grad_out; red.s_den = loss_cnt + 1; red.s_mul = 2.f;
     HIPCHK(umlh_enc_launch_multi_reduce(&red, st), "seq bwd (reduce)");
+    return UMLH_OK;
+}
+
+// SequenceInfoNCELoss (MultiBench/models.py:145-175) over n valid rows
+int umlh_infonce_forward(const float* pred, const float* target, int32_t n, int32_t D, float temperature, float* pred_hat,
+                         float* target_hat, float* pred_norm, float* probs, float* row_loss, float* loss, void* stream) {
+    if (!pred || !target || !pred_hat || !target_hat || !pred_norm || !probs || !row_loss || !loss)
+        return fail(UMLH_E_INVALID, "umlh_infonce_forward: null buffer");
+    if (n < 1 || D < 1 || !(temperature > 0.f)) return fail(UMLH_E_INVALID, "umlh_infonce_forward: bad shape (n=%d D=%d)", n, D);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(umlh_seq_launch_l2norm(pred, n, D, pred_hat, pred_norm, st), "infonce l2norm(pred)");
+    HIPCHK(umlh_seq_launch_l2norm(target, n, D, target_hat, row_loss, st), "infonce l2norm(target)");   // (row_loss: scratch for the unused norms)
+    int ns = 1;
+    const int rc = umlh_gemm_f32_epi(pred_hat, target_hat, probs, n, n, D, D, D, 0, 0, nullptr, 1, nullptr, 0, &ns, st);
+    if (rc) return rc;
+    HIPCHK(umlh_seq_launch_nce_rows(probs, n, 1.f / temperature, row_loss, loss, st), "infonce rows");
+    return UMLH_OK;
+}
+
+int umlh_infonce_backward(const float* pred_hat, const float* target_hat, const float* pred_norm, const float* probs,
+                          const float* grad_out, int32_t n, int32_t D, float temperature, float* dhat, float* dpred, void* stream) {
+    if (!pred_hat || !target_hat || !pred_norm || !probs || !grad_out || !dhat || !dpred)
+        return fail(UMLH_E_INVALID, "umlh_infonce_backward: null buffer");
+    if (n < 1 || D < 1 || !(temperature > 0.f)) return fail(UMLH_E_INVALID, "umlh_infonce_backward: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    int ns = 1;
+    const int rc = umlh_gemm_f32_epi(probs, target_hat, dhat, n, D, n, n, D, 0, 1, nullptr, 1, nullptr, 0, &ns, st);   // dhat = (softmax - I) target_hat
+    if (rc) return rc;
+    HIPCHK(umlh_seq_launch_l2norm_bwd(dhat, pred_hat, pred_norm, grad_out, 1.f / ((float)n * temperature), n, D, dpred, st), "infonce l2norm bwd");
     return UMLH_OK;
 }
 

@@ -143,3 +143,92 @@ int umlh_seq_launch_bwd(const float* z, const float* w, const float* dres, const
     return (int)hipGetLastError();
 }
 }
+
+// --------------------------------------------------------------------------- //
+// SequenceInfoNCELoss (MultiBench/models.py:145-175): rows = the valid (batch, time) positions, logits = normalize(pred) .
+// normalize(target)^T / temperature, labels = the diagonal, loss = mean cross-entropy.  The n x n logits come from the fp32 GEMM;
+// these are the row kernels around it.
+// --------------------------------------------------------------------------- //
+__device__ __forceinline__ float nce_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float nce_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// y[r] = x[r] / max(|x[r]|, 1e-12) (F.normalize), norm[r] = that denominator; a wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, int n, int D, float* __restrict__ y,
+                                                          float* __restrict__ norm) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) { const float v = x[(size_t)r * D + d]; s = fmaf(v, v, s); }
+    const float den = fmaxf(sqrtf(nce_wave_sum(s)), 1e-12f);
+    for (int d = lane; d < D; d += 64) y[(size_t)r * D + d] = x[(size_t)r * D + d] / den;
+    if (lane == 0) norm[r] = den;
+}
+
+// row r of the raw dot products: l = dots / temperature; row_loss[r] = logsumexp(l) - l[r]; the row is overwritten with
+// softmax(l) - onehot(r)  (d loss_r / d l)
+__global__ __launch_bounds__(256) void nce_rows_kernel(float* __restrict__ dots, int n, float inv_temp, float* __restrict__ row_loss) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float* row = dots + (size_t)r * n;
+    float mx = -__builtin_huge_valf();
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, row[j] * inv_temp);
+    mx = nce_wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += __expf(row[j] * inv_temp - mx);
+    s = nce_wave_sum(s);
+    const float lse = mx + __logf(s), diag = row[r] * inv_temp;
+    for (int j = lane; j < n; j += 64) row[j] = __expf(row[j] * inv_temp - lse) - (j == r ? 1.f : 0.f);
+    if (lane == 0) row_loss[r] = lse - diag;
+}
+
+// loss = mean of row_loss (one block, fixed order)
+__global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restrict__ row_loss, int n, float* __restrict__ loss) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += row_loss[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = sh[0] / (float)n;
+}
+
+// gradient through F.normalize: dx = c * (dy - y (y . dy)) / norm, c = grad_out * scale (scale = 1 / (n * temperature))
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ norm, const float* __restrict__ grad_out,
+                                                         float scale, int n, int D, float* __restrict__ dx) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot = fmaf(y[(size_t)r * D + d], dy[(size_t)r * D + d], dot);
+    dot = nce_wave_sum(dot);
+    const float c = grad_out[0] * scale / norm[r];
+    for (int d = lane; d < D; d += 64) dx[(size_t)r * D + d] = c * (dy[(size_t)r * D + d] - y[(size_t)r * D + d] * dot);
+}
+
+extern "C" {
+int umlh_seq_launch_l2norm(const float* x, int n, int D, float* y, float* norm, hipStream_t st) {
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, n, D, y, norm);
+    return (int)hipGetLastError();
+}
+int umlh_seq_launch_nce_rows(float* dots, int n, float inv_temp, float* row_loss, float* loss, hipStream_t st) {
+    hipLaunchKernelGGL(nce_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, dots, n, inv_temp, row_loss);
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, st, row_loss, n, loss);
+    return (int)hipGetLastError();
+}
+int umlh_seq_launch_l2norm_bwd(const float* dy, const float* y, const float* norm, const float* grad_out, float scale, int n, int D,
+                               float* dx, hipStream_t st) {
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, st, dy, y, norm, grad_out, scale, n, D, dx);
+    return (int)hipGetLastError();
+}
+}

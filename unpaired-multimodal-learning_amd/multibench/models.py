@@ -97,8 +97,47 @@ class MSE(nn.Module):
         return ((predictions - targets) ** 2 * m).sum() / (m.sum() + 1e-8)
 
 
+class _InfoNCE(torch.autograd.Function):
+    """mean CE of normalize(p) normalize(t)^T / temperature against the diagonal (umlh_infonce_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, p, t, temperature):
+        import umlh
+        lib = umlh.load_library()
+        p, t = (v.detach().to(torch.float32).contiguous() for v in (p, t))
+        n, D = p.shape
+        dev = p.device
+        phat, that = torch.empty_like(p), torch.empty_like(t)
+        pnorm, row_loss = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+        probs = torch.empty(n, n, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        vp = lambda v: C.c_void_p(v.data_ptr())
+        umlh._lib.check(lib.umlh_infonce_forward(vp(p), vp(t), n, D, float(temperature), vp(phat), vp(that), vp(pnorm), vp(probs), vp(row_loss),
+                                                 vp(loss), st), "umlh_infonce_forward")
+        ctx.save_for_backward(phat, that, pnorm, probs)
+        ctx.temperature = float(temperature)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        import umlh
+        lib = umlh.load_library()
+        phat, that, pnorm, probs = ctx.saved_tensors
+        n, D = phat.shape
+        g = g.detach().to(torch.float32).reshape(1).contiguous()
+        dhat, dp = torch.empty_like(phat), torch.empty_like(phat)
+        st = C.c_void_p(torch.cuda.current_stream(phat.device).cuda_stream)
+        vp = lambda v: C.c_void_p(v.data_ptr())
+        umlh._lib.check(lib.umlh_infonce_backward(vp(phat), vp(that), vp(pnorm), vp(probs), vp(g), n, D, ctx.temperature, vp(dhat), vp(dp), st),
+                        "umlh_infonce_backward")
+        return dp, None, None
+
+
 class SequenceInfoNCELoss(nn.Module):
-    """Contrastive alternative to the MSE critic (models.py:145-175); torch ops."""
+    """Contrastive alternative to the MSE critic (models.py:145-175).  The valid rows are selected as the reference does
+    (boolean indexing: data formatting, torch); normalisation, the n x n logits, the cross-entropy and their backward run on
+    the HIP op.  Targets are model inputs: no gradient flows to them."""
 
     def __init__(self, temperature=0.07):
         super().__init__()
@@ -109,8 +148,9 @@ class SequenceInfoNCELoss(nn.Module):
             p, t = predictions[mask.bool()], targets[mask.bool()]
         else:
             p, t = predictions.flatten(0, 1), targets.flatten(0, 1)
-        logits = F.normalize(p, dim=-1) @ F.normalize(t, dim=-1).T / self.temperature
-        return F.cross_entropy(logits, torch.arange(logits.shape[0], device=logits.device))
+        if not p.is_cuda:
+            raise RuntimeError("SequenceInfoNCELoss runs on the HIP kernels only: move the inputs to the GPU")
+        return _InfoNCE.apply(p, t.detach(), self.temperature)
 
 
 class _DecoderNextStepMSE(torch.autograd.Function):

@@ -26,7 +26,7 @@ EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_w
            "umlh_apply_update", "umlh_eval_batch", "umlh_eval_rows", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
            "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_comm_unique_id", "umlh_comm_init_rank",
-           "umlh_set_comm", "umlh_set_allreduce", "umlh_seq_mse_forward", "umlh_seq_mse_backward", "umlh_seq_mse_backward_scratch_floats",
+           "umlh_set_comm", "umlh_set_allreduce", "umlh_seq_mse_forward", "umlh_seq_mse_backward", "umlh_seq_mse_backward_scratch_floats", "umlh_infonce_forward", "umlh_infonce_backward",
            "umlh_random_permutation", "umlh_debug_buffer",
            "umlh_gemm_f32", "umlh_add_inplace", "umlh_bias_act", "umlh_relu_backward", "umlh_dropout", "umlh_colsum",
            "umlh_add_layernorm_forward", "umlh_layernorm_backward", "umlh_add_positions", "umlh_positions_backward",
@@ -189,6 +189,8 @@ def load_library():
     lib.umlh_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32]
     lib.umlh_seq_mse_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.umlh_seq_mse_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.umlh_infonce_forward.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp, vp]
+    lib.umlh_infonce_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp]
     lib.umlh_seq_mse_backward_scratch_floats.restype = u64
     lib.umlh_seq_mse_backward_scratch_floats.argtypes = [i32, i32, i32, i32]
     lib.umlh_random_permutation.argtypes = [i64, u64, vp, vp]
