@@ -95,6 +95,7 @@ struct GemmArgs {
     // > 0: modality-aligned split-K -- slabs [0, nsplit1) cover k in [0, k_switch) and the rest cover
     // [k_switch, K), k_chunk rows each (image and text gradients stay in separate slabs); 0: uniform
     int   nsplit1;
+    int   slab_count;            // dw_f32 only: slabs of the launch (its grid is 1-D, split index fastest)
     Epilogue epi;                // applied by the kernel when the launch has ONE slab (a split-K launch leaves it to the reduce)
 };
 

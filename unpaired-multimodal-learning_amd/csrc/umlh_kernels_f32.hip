@@ -497,6 +497,187 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
 }
 
 // --------------------------------------------------------------------------- //
+// dw_f32: dW = dZ^T F  (TA = 0, TB = 1 of gemm_f32's contract: A[m][k] k-contiguous, B rows gathered by reduction index,
+// two sources, modality-aligned split-K) for the big-batch fp32 step.  128x128 tile, 4 waves of 64x64 (2x2 MFMA tiles).
+// Against gemm_f32<0,1,1> (64x64 tiles, 114 us at cfg2): half the L2->CU bytes per flop, and the LDS tiles are
+// [row][k] with a 20-float stride so that the 8 k-steps of a 16-row chunk of one MFMA operand are TWO ds_read_b128
+// (lane half h takes k = 8h .. 8h+7 of the chunk -- the k order inside a chunk is free as long as A and B agree):
+// 8 LDS reads per 32 MFMAs instead of 64 scalar ones.  All global loads are branch-free (clamped addresses; rows past
+// M / columns past N only feed outputs that are never stored; masked reduction rows are zeroed by selects one
+// iteration after the load was issued).
+// --------------------------------------------------------------------------- //
+constexpr int DWKC = 32;                                  // reduction rows per staged chunk (one 128-B line of a dZ^T row)
+constexpr int DWLD = DWKC + 4;                            // floats per LDS row (b128 reads of 16 lanes cover all 64 banks)
+constexpr int DWKIDS = 2048;                              // reduction rows per split whose row ids fit the LDS table
+constexpr size_t DW_SMEM = sizeof(float) * 4 * 128 * DWLD + sizeof(int) * DWKIDS;
+__global__ __launch_bounds__(256) void dw_f32(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+    float* const As2 = dw_smem;                           // [2][128 * DWLD]
+    float* const Bs2 = dw_smem + 2 * 128 * DWLD;          // [2][128 * DWLD]
+    int* const kid = reinterpret_cast<int*>(dw_smem + 4 * 128 * DWLD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+    // 1-D grid, split index fastest: workgroups are dealt to the 8 XCDs round-robin, so with 8 (or 16) splits every tile of
+    // one K range runs on ONE XCD and its dZ^T columns / feature rows are fetched into that XCD's L2 once (with the tile
+    // index fastest, the 4 column tiles sharing a dZ^T row block sat on 4 different XCDs)
+    const int nsplit = (int)g.slab_count, z = blockIdx.x % nsplit, tile = blockIdx.x / nsplit, ntx = (g.N + 127) / 128;
+    const int m0 = (tile / ntx) * 128, n0 = (tile % ntx) * 128;
+    int kb = z * g.k_chunk, ke = min(g.K, kb + g.k_chunk);
+    if (g.nsplit1 > 0) {                                  // modality-aligned split-K
+        if (z < g.nsplit1) ke = min(g.k_switch, kb + g.k_chunk);
+        else { kb = g.k_switch + (z - g.nsplit1) * g.k_chunk; ke = min(g.K, kb + g.k_chunk); }
+    }
+    auto kvalid = [&](int k) -> bool { return k < g.k_switch ? (k < g.k_valid1) : (k - g.k_switch < g.k_valid2); };
+    for (int i = tid; i < ke - kb; i += 256) {            // gathered row id of every reduction row of this split; -1 = masked
+        const int k = kb + i;
+        int rid = -1;
+        if (kvalid(k)) {
+            if (k < g.k_switch) rid = g.k_rows ? (int)g.k_rows[k] : k;
+            else { const int kl = k - g.k_switch; rid = g.k_rows2 ? (int)g.k_rows2[kl] : kl; }
+        }
+        kid[i] = rid;
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // A pieces (4 per thread): row ar + 32q of the tile, k columns 4*akq .. +3 of the chunk (8 lanes = one 128-B line)
+    const int ar = tid >> 3, akq = tid & 7;
+    const float* a_row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_row[q] = g.A + (size_t)min(m0 + ar + 32 * q, g.M - 1) * g.lda;
+    // B pieces (4 per thread): reduction row bk of the chunk, columns 4*bnq + 32q .. +3 of the tile
+    const int bk = tid & 31, bnq = tid >> 5;
+    int b_col[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b_col[q] = min(n0 + 4 * bnq + 32 * q, g.N - 4);
+    f32x4v areg[4], breg[4];
+    int a_k = 0;                                          // first reduction index of the staged A pieces (for the masks)
+    bool b_ok = false;
+    const float* b_row = g.B;
+    auto gload_a = [&](int k0) {
+        a_k = k0 + 4 * akq;
+        const int kc = min(a_k, g.lda - 4);               // (only reduction indices >= K are ever clamped: masked below)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) areg[q] = *reinterpret_cast<const f32x4v*>(a_row[q] + kc);
+    };
+    auto gload_b_row = [&](int k0) {
+        const int k = k0 + bk;
+        const int rid = kid[min(k, ke - 1) - kb];
+        b_ok = (k < ke) & (rid >= 0);
+        const bool s2 = k >= g.k_switch;
+        const float* row = (s2 ? g.B2 : g.B) + (size_t)max(rid, 0) * (s2 ? g.ldb2 : g.ldb);
+        b_row = b_ok ? row : g.B;
+    };
+    auto gload_b = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) breg[q] = *reinterpret_cast<const f32x4v*>(b_row + b_col[q]);
+    };
+    bool av[4];
+    auto lstore_masks = [&]() {                           // validity of the 4 reduction indices of the staged A pieces (no branches)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = a_k + j;
+            const bool first = k < g.k_switch;
+            av[j] = (k < ke) & ((first ? k : k - g.k_switch) < (first ? g.k_valid1 : g.k_valid2));
+        }
+    };
+    auto lstore_piece = [&](int buf, int q) {
+        float* As = As2 + buf * 128 * DWLD;
+        float* Bs = Bs2 + buf * 128 * DWLD;
+        f32x4v v = areg[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = av[j] ? v[j] : 0.f;
+        *reinterpret_cast<f32x4v*>(&As[(ar + 32 * q) * DWLD + 4 * akq]) = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[(4 * bnq + 32 * q + j) * DWLD + bk] = b_ok ? breg[q][j] : 0.f;
+    };
+    // One chunk = 64 MFMAs per wave (4096 cycles of the SIMD's matrix pipe) with ONE wave per SIMD: nothing else hides the
+    // staging, and a block of ~150 staging instructions between two MFMA groups lets the pipe run dry (an MFMA occupies it
+    // for 64 cycles = 16 issue slots).  So the LDS stores of chunk c+1 and the global loads of chunk c+2 are dealt out one
+    // piece per MFMA step between the 16 steps of chunk c, the order pinned with sched_barrier.
+    // Lane half h multiplies k = 16h .. 16h+15 of the chunk: 4 ds_read_b128 per operand tile.
+    f32x4v a[2][4], b[2][4];
+    auto mfma_step = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s >> 2][s & 3], b[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (kb < ke) {
+        gload_a(kb); gload_b_row(kb); gload_b();
+        lstore_masks();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lstore_piece(0, q);
+        if (kb + DWKC < ke) { gload_a(kb + DWKC); gload_b_row(kb + DWKC); gload_b(); }
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += DWKC) {
+        const float* As = As2 + buf * 128 * DWLD + (wm * 64 + l31) * DWLD + 16 * h;
+        const float* Bs = Bs2 + buf * 128 * DWLD + (wn * 64 + l31) * DWLD + 16 * h;
+        auto frag = [&](int v) {                          // operands of MFMA steps 4v .. 4v+3 (4 ds_read_b128)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][v] = *reinterpret_cast<const f32x4v*>(As + i * 32 * DWLD + 4 * v);
+                b[i][v] = *reinterpret_cast<const f32x4v*>(Bs + i * 32 * DWLD + 4 * v);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const bool st1 = k0 + DWKC < ke, ld2 = k0 + 2 * DWKC < ke;
+        frag(0);
+        frag(1);                                          // (the reads of steps 4v.. go out while steps 4(v-1).. multiply)
+        mfma_step(0);
+        if (st1) lstore_masks();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(1);
+        frag(2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                     // chunk c+1 (in registers) -> the other buffer, a piece per step
+            if (st1) lstore_piece(buf ^ 1, q);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(2 + q);
+        }
+        frag(3);
+        if (ld2) gload_a(k0 + 2 * DWKC);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(6);
+        if (ld2) gload_b_row(k0 + 2 * DWKC);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(7);
+        mfma_step(8);
+        if (ld2) gload_b();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 9; s2 < 16; ++s2) mfma_step(s2);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = g.out + (size_t)z * g.slab_stride;
+    const float alpha = g.alpha * (g.alpha_ptr ? *g.alpha_ptr : 1.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row(e, h);
+                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][j][e] * alpha;
+            }
+        }
+}
+
+// --------------------------------------------------------------------------- //
 // gemm_enc: the dense layers of the MultiBench encoder (no row gathers).  Same contract as gemm_f32 with a 64x64 tile,
 // but the K range is staged 64 reduction rows at a time and the NEXT 64 are already in flight while a chunk is multiplied:
 // these GEMMs are short (K = 40 .. 300, or a split-K range of 64-128 rows of a 1600 / 2048 long reduction) and tiny, so
@@ -989,8 +1170,33 @@ int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t
     return (int)hipErrorInvalidValue;
 }
 
+static bool dw_f32_applies(const GemmArgs* g, int ta, int tb) {
+    static const bool off = [] { const char* e = getenv("UMLH_F32_DW"); return e && atoi(e) == 0; }();   // timing comparisons
+    if (off || ta != 0 || tb != 1 || g->a_rows || g->epi.on) return false;
+    if ((long long)g->M * g->N < 8LL * 128 * 128 || g->N < 4 || g->N % 4 || g->lda < 4) return false;
+    if (g->k_chunk > DWKIDS) return false;
+    if (g->lda % 4 || g->ldb % 4 || (reinterpret_cast<uintptr_t>(g->A) & 15) || (reinterpret_cast<uintptr_t>(g->B) & 15)) return false;
+    if (g->B2 && (g->ldb2 % 4 || (reinterpret_cast<uintptr_t>(g->B2) & 15))) return false;
+    if (!g->B2 && g->k_switch < g->K) return false;
+    return true;
+}
+
 int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream) {
     if (g->M <= 0 || g->N <= 0) return 0;
+    if (dw_f32_applies(g, ta, tb)) {
+        int dev = 0;
+        static unsigned attr_done = 0;                    // per-device bit: the kernel's dynamic LDS limit is raised once
+        if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+        if (dev < 32 && !(attr_done & (1u << dev))) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM);
+            if (e != hipSuccess) return (int)e;
+            attr_done |= 1u << dev;
+        }
+        GemmArgs a = *g;
+        a.slab_count = splits;
+        hipLaunchKernelGGL(dw_f32, dim3(((g->N + 127) / 128) * ((g->M + 127) / 128) * splits), dim3(256), DW_SMEM, stream, a);
+        return (int)hipGetLastError();
+    }
     // 64x64 tiles when the 128x128 grid would leave most of the 256 CUs with a single 4-wave workgroup
     long long wg128 = (long long)((g->N + 127) / 128) * ((g->M + 127) / 128) * splits;
     static const int tm_env = [] { const char* e = getenv("UMLH_F32_TM"); return e ? atoi(e) : 0; }();   // tile override for tuning runs
