@@ -179,97 +179,135 @@ def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def _enc_forward(x, lengths, cfg, conv_w, pos, lp):
+    """One pass of the shared encoder: x [B,T,F] -> conv -> (+pos) -> layer stack -> output rows.  Returns (out, state);
+    `state` is what `_enc_backward` needs (it holds the plan lease: the saved activations live in the plan)."""
+    lib = umlh.load_library()
+    dev = x.device
+    B, T, F = x.shape
+    H, p, eps, seed = cfg["H"], cfg["p"], cfg["eps"], cfg["seed"]
+    st = _st(dev)
+    x2d = _f32(x).reshape(B * T, F)
+    lens = None if lengths is None else lengths.to(device=dev, dtype=torch.int64).contiguous()
+    ar_b = torch.arange(B, device=dev, dtype=torch.int64)
+    ar_t = torch.arange(T, device=dev, dtype=torch.int64)
+    rows_tb = (ar_b.unsqueeze(0) * T + ar_t.unsqueeze(1)).reshape(-1).contiguous()      # token row m=(t,b) -> source row b*T+t
+    rows_bt = (ar_t.unsqueeze(0) * B + ar_b.unsqueeze(1)).reshape(-1).contiguous()      # source row (b,t) -> token row t*B+b
+    M = T * B
+    n_layers = len(lp) // N_LAYER_PARAMS
+    Z = conv_w.shape[0] if conv_w is not None else F
+    dff = lp[4].shape[0] if n_layers else 0
+    lease = plan = None
+    if n_layers:
+        # the layer stack runs on a leased plan: fixed buffers, one HIP-graph launch per direction
+        key = (dev.index, T, B, Z, H, dff, float(p), float(eps), n_layers, lens is not None, tuple(t.data_ptr() for t in lp))
+        lease = _lease_plan(key, lambda: _Plan(_layer_cfg(T, B, Z, H, dff, p, eps, 0), n_layers, lp, lens is not None, dev))
+        plan = lease.plan
+    if conv_w is not None:
+        cw = _f32(conv_w).reshape(conv_w.shape[0], -1)
+        h = linear_forward(x2d, cw, None, a_rows=rows_tb, rows=M, out=None if plan is None else plan.h0)     # [M, Z]
+    else:
+        cw = None
+        h = torch.empty(M, F, dtype=torch.float32, device=dev) if plan is None else plan.h0
+        check(lib.umlh_gather_rows(_p(x2d), _p(rows_tb), M, F, _p(h), 0, st), "umlh_gather_rows")
+    if pos is not None:
+        check(lib.umlh_add_positions(_p(h), _p(_f32(pos)), T, B, Z, st), "umlh_add_positions")
+    if plan is not None:
+        if lens is not None:
+            plan.lens.copy_(lens)
+        check(lib.umlh_encoder_plan_forward(plan.handle, C.c_uint64(int(seed) & (2 ** 64 - 1)), st), "umlh_encoder_plan_forward")
+        h = plan.h_last
+    mode = cfg["out_mode"]
+    if mode == "all":
+        idx, n_out = rows_bt, M
+    elif mode == "last_len":
+        idx, n_out = ((lens - 1) * B + ar_b).contiguous(), B
+    else:
+        idx, n_out = ((T - 1) * B + ar_b).contiguous(), B
+    out = torch.empty(n_out, Z, dtype=torch.float32, device=dev)
+    check(lib.umlh_gather_rows(_p(h), _p(idx), n_out, Z, _p(out), 0, st), "umlh_gather_rows")
+    state = ((B, T, F, Z, M), x2d, rows_tb, rows_bt, idx, cw, pos is not None and pos.requires_grad, lease, x.requires_grad)
+    return (out.reshape(B, T, Z) if mode == "all" else out), state
+
+
+def _enc_backward(state, g_out):
+    """Backward of one pass.  Returns (dx, dconv, dpos, flat) -- `flat` is the PLAN's flat gradient buffer of all layer
+    parameters (rewritten by the plan's next backward: the caller copies or sums it), None without layers."""
+    lib = umlh.load_library()
+    (B, T, F, Z, M), x2d, rows_tb, rows_bt, idx, cw, need_dpos, lease, need_dx = state
+    dev = g_out.device
+    st = _st(dev)
+    g = _f32(g_out).reshape(-1, Z)
+    plan = None if lease is None else lease.plan
+    dh = torch.zeros(M, Z, dtype=torch.float32, device=dev) if plan is None else plan.dh_out.zero_()
+    check(lib.umlh_gather_rows(_p(g), _p(idx), g.shape[0], Z, _p(dh), 1, st), "umlh_gather_rows(scatter)")
+    flat = None
+    if plan is not None:
+        check(lib.umlh_encoder_plan_backward(plan.handle, st), "umlh_encoder_plan_backward")
+        flat, dh = plan.grads, plan.dh0
+    dpos = None
+    if need_dpos:                                        # learnable position table only
+        dpos = torch.empty(T, Z, dtype=torch.float32, device=dev)
+        check(lib.umlh_positions_backward(_p(dh), T, B, Z, _p(dpos), st), "umlh_positions_backward")
+    dconv = dx = None
+    if cw is not None:
+        dx, dconv, _ = linear_backward(x2d, cw, dh, need_dx=need_dx, has_bias=False, x_rows=rows_tb, dx_rows=rows_bt, n_dx_rows=B * T)
+        dconv = dconv.reshape(cw.shape[0], cw.shape[1], 1)
+    elif need_dx:
+        dx = torch.empty(B * T, F, dtype=torch.float32, device=dev)
+        check(lib.umlh_gather_rows(_p(dh), _p(rows_bt), B * T, F, _p(dx), 0, st), "umlh_gather_rows")
+    if dx is not None:
+        dx = dx.reshape(B, T, F)
+    return dx, dconv, dpos, flat
+
+
+def _split_flat(flat, lp):
+    grads, o = [], 0
+    for t in lp:
+        grads.append(flat[o:o + t.numel()].view(t.shape))
+        o += t.numel()
+    return grads
+
+
 class EncoderFn(torch.autograd.Function):
-    """x [B,T,F] -> conv -> (+pos) -> layers -> output rows.  ``cfg`` = dict(T, B, H, p, eps, seed, out_mode)
+    """x [B,T,F] -> conv -> (+pos) -> layers -> output rows.  ``cfg`` = dict(H, p, eps, seed, out_mode)
     with out_mode 'last_len' | 'last' | 'all'; ``params`` = conv_w | None, pos [T,Z] | None, then 12 tensors per layer."""
 
     @staticmethod
     def forward(ctx, x, lengths, cfg, conv_w, pos, *layer_params):
-        lib = umlh.load_library()
-        dev = x.device
-        B, T, F = x.shape
-        H, p, eps, seed = cfg["H"], cfg["p"], cfg["eps"], cfg["seed"]
-        st = _st(dev)
-        x2d = _f32(x).reshape(B * T, F)
-        lens = None if lengths is None else lengths.to(device=dev, dtype=torch.int64).contiguous()
-        ar_b = torch.arange(B, device=dev, dtype=torch.int64)
-        ar_t = torch.arange(T, device=dev, dtype=torch.int64)
-        rows_tb = (ar_b.unsqueeze(0) * T + ar_t.unsqueeze(1)).reshape(-1).contiguous()      # token row m=(t,b) -> source row b*T+t
-        rows_bt = (ar_t.unsqueeze(0) * B + ar_b.unsqueeze(1)).reshape(-1).contiguous()      # source row (b,t) -> token row t*B+b
-        M = T * B
-        n_layers = len(layer_params) // N_LAYER_PARAMS
         lp = [_f32(t) for t in layer_params]
-        Z = conv_w.shape[0] if conv_w is not None else F
-        dff = lp[4].shape[0] if n_layers else 0
-        lease = plan = None
-        if n_layers:
-            # the layer stack runs on a leased plan: fixed buffers, one HIP-graph launch per direction
-            key = (dev.index, T, B, Z, H, dff, float(p), float(eps), n_layers, lens is not None, tuple(t.data_ptr() for t in lp))
-            lease = _lease_plan(key, lambda: _Plan(_layer_cfg(T, B, Z, H, dff, p, eps, 0), n_layers, lp, lens is not None, dev))
-            plan = lease.plan
-        if conv_w is not None:
-            cw = _f32(conv_w).reshape(conv_w.shape[0], -1)
-            h = linear_forward(x2d, cw, None, a_rows=rows_tb, rows=M, out=None if plan is None else plan.h0)     # [M, Z]
-        else:
-            cw = None
-            h = torch.empty(M, F, dtype=torch.float32, device=dev) if plan is None else plan.h0
-            check(lib.umlh_gather_rows(_p(x2d), _p(rows_tb), M, F, _p(h), 0, st), "umlh_gather_rows")
-        if pos is not None:
-            check(lib.umlh_add_positions(_p(h), _p(_f32(pos)), T, B, Z, st), "umlh_add_positions")
-        if plan is not None:
-            if lens is not None:
-                plan.lens.copy_(lens)
-            check(lib.umlh_encoder_plan_forward(plan.handle, C.c_uint64(int(seed) & (2 ** 64 - 1)), st), "umlh_encoder_plan_forward")
-            h = plan.h_last
-        mode = cfg["out_mode"]
-        if mode == "all":
-            idx, n_out = rows_bt, M
-        elif mode == "last_len":
-            idx, n_out = ((lens - 1) * B + ar_b).contiguous(), B
-        else:
-            idx, n_out = ((T - 1) * B + ar_b).contiguous(), B
-        out = torch.empty(n_out, Z, dtype=torch.float32, device=dev)
-        check(lib.umlh_gather_rows(_p(h), _p(idx), n_out, Z, _p(out), 0, st), "umlh_gather_rows")
-        ctx.cfg, ctx.dims = cfg, (B, T, F, Z, M, n_layers)
-        ctx.aux = (x2d, rows_tb, rows_bt, idx, cw, pos is not None, lp, lease)
-        ctx.need_dx = x.requires_grad
-        return out.reshape(B, T, Z) if mode == "all" else out
+        out, ctx.state = _enc_forward(x, lengths, cfg, conv_w, pos, lp)
+        ctx.lp = lp
+        return out
 
     @staticmethod
     def backward(ctx, g_out):
-        lib = umlh.load_library()
-        cfg = ctx.cfg
-        B, T, F, Z, M, n_layers = ctx.dims
-        x2d, rows_tb, rows_bt, idx, cw, has_pos, lp, lease = ctx.aux
-        dev = g_out.device
-        st = _st(dev)
-        g = _f32(g_out).reshape(-1, Z)
-        plan = None if lease is None else lease.plan
-        dh = torch.zeros(M, Z, dtype=torch.float32, device=dev) if plan is None else plan.dh_out.zero_()
-        check(lib.umlh_gather_rows(_p(g), _p(idx), g.shape[0], Z, _p(dh), 1, st), "umlh_gather_rows(scatter)")
-        grads = []
-        if plan is not None:
-            check(lib.umlh_encoder_plan_backward(plan.handle, st), "umlh_encoder_plan_backward")
-            flat, o = plan.grads.clone(), 0                 # the plan's buffers are rewritten by its next backward
-            for t in lp:
-                grads.append(flat[o:o + t.numel()].view(t.shape))
-                o += t.numel()
-            dh = plan.dh0
-        dpos = None
-        if has_pos:
-            dpos = torch.empty(T, Z, dtype=torch.float32, device=dev)
-            check(lib.umlh_positions_backward(_p(dh), T, B, Z, _p(dpos), st), "umlh_positions_backward")
-        dconv = dx = None
-        if cw is not None:
-            dx, dconv, _ = linear_backward(x2d, cw, dh, need_dx=ctx.need_dx, has_bias=False, x_rows=rows_tb, dx_rows=rows_bt,
-                                           n_dx_rows=B * T)
-            dconv = dconv.reshape(cw.shape[0], cw.shape[1], 1)
-        elif ctx.need_dx:
-            dx = torch.empty(B * T, F, dtype=torch.float32, device=dev)
-            check(lib.umlh_gather_rows(_p(dh), _p(rows_bt), B * T, F, _p(dx), 0, st), "umlh_gather_rows")
-        if dx is not None:
-            dx = dx.reshape(B, T, F)
+        dx, dconv, dpos, flat = _enc_backward(ctx.state, g_out)
+        grads = _split_flat(flat.clone(), ctx.lp) if flat is not None else []     # the plan's buffer is rewritten by its next backward
         return (dx, None, None, dconv, dpos, *grads)
+
+
+class EncoderPairFn(torch.autograd.Function):
+    """Both modality passes of the alternation step through the SHARED encoder as one autograd node (MultiBench/models.py:
+    200,232 call the same module twice): the two passes run exactly as two EncoderFn calls would, but the gradients of the
+    shared parameters are summed here by one kernel over the two flat buffers instead of 62 per-tensor accumulations in
+    autograd's AccumulateGrad."""
+
+    @staticmethod
+    def forward(ctx, x, lx, cfg_x, y, ly, cfg_y, conv_w, pos_x, pos_y, *layer_params):
+        lp = [_f32(t) for t in layer_params]
+        ox, ctx.sx = _enc_forward(x, lx, cfg_x, conv_w, pos_x, lp)
+        oy, ctx.sy = _enc_forward(y, ly, cfg_y, conv_w, pos_y, lp)
+        ctx.lp = lp
+        return ox, oy
+
+    @staticmethod
+    def backward(ctx, gx, gy):
+        dx, dcx, dpx, fx = _enc_backward(ctx.sx, gx)
+        dy, dcy, dpy, fy = _enc_backward(ctx.sy, gy)
+        grads = _split_flat(fx + fy, ctx.lp) if fx is not None else []
+        dconv = None if dcx is None else dcx + dcy
+        return (dx, None, None, dy, None, None, dconv, dpx, dpy, *grads)
 
 
 class LinearFn(torch.autograd.Function):

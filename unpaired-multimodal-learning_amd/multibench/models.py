@@ -62,10 +62,8 @@ class Transformer(nn.Module):
             g.manual_seed((torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) % (2 ** 63))
         return int(torch.randint(0, 2 ** 62, (1,), generator=g).item())
 
-    def forward(self, x, lengths=None):
-        """models.py:75-127 on the HIP encoder (multibench/encoder.py): conv1d -> positions -> causal
-        transformer layers under the key-padding mask -> last valid token / all tokens."""
-        from .encoder import EncoderFn, layer_params
+    def _prepare(self, x, lengths):
+        """Arguments of one encoder pass (models.py:75-127): truncated input, positions, dropout / mask configuration."""
         if type(x) is list:
             x = x[0]
         if not x.is_cuda:
@@ -76,14 +74,35 @@ class Transformer(nn.Module):
         pos = None
         if self.pos_embd:
             pos = self.pos_embedding.weight[:T] if self.pos_learnable else self.pos_table[:T]
-        layers = self.transformer.layers
-        l0 = layers[0]
+        l0 = self.transformer.layers[0]
         p = float(l0.dropout.p) if self.training else 0.0
         seed = self._dropout_seed() if p > 0.0 else 0
         cfg = {"H": l0.self_attn.num_heads, "p": p, "eps": float(l0.norm1.eps), "seed": seed,
                "out_mode": ("last_len" if lengths is not None else "last") if self.out_last else "all"}
-        params = [t for layer in layers for t in layer_params(layer)]
-        return EncoderFn.apply(x, lengths, cfg, self.conv.weight if self.conv1d else None, pos, *params)
+        return x, pos, cfg
+
+    def _params(self):
+        from .encoder import layer_params
+        return [t for layer in self.transformer.layers for t in layer_params(layer)]
+
+    def forward(self, x, lengths=None):
+        """models.py:75-127 on the HIP encoder (multibench/encoder.py): conv1d -> positions -> causal
+        transformer layers under the key-padding mask -> last valid token / all tokens."""
+        from .encoder import EncoderFn
+        x, pos, cfg = self._prepare(x, lengths)
+        return EncoderFn.apply(x, lengths, cfg, self.conv.weight if self.conv1d else None, pos, *self._params())
+
+    def forward_pair(self, x, x_lengths, y, y_lengths):
+        """The two calls `encoder(x_proj, lengths=x_lengths)`, `encoder(y_proj, lengths=y_lengths)` of the alternation step
+        (models.py:200,232) as one autograd node: same arithmetic and dropout streams as two `forward` calls in this order,
+        the shared parameters' gradients summed once (encoder.EncoderPairFn)."""
+        from .encoder import EncoderPairFn
+        if self.pos_embd and self.pos_learnable:                              # (a learnable table is a parameter too: keep its
+            return self.forward(x, x_lengths), self.forward(y, y_lengths)     #  two gradient contributions on autograd's path)
+        x, pos_x, cfg_x = self._prepare(x, x_lengths)
+        y, pos_y, cfg_y = self._prepare(y, y_lengths)
+        return EncoderPairFn.apply(x, x_lengths, cfg_x, y, y_lengths, cfg_y, self.conv.weight if self.conv1d else None,
+                                   pos_x, pos_y, *self._params())
 
 
 class MSE(nn.Module):
@@ -209,10 +228,8 @@ class UML(nn.Module):
         self.infoNCE_loss = infoNCE_loss
         self.y_critic = SequenceInfoNCELoss() if infoNCE_loss else MSE()
 
-    def _branch(self, x, proj, dec, lengths, enc_lengths, use_nce):
-        x = x.unsqueeze(1).float() if x.ndim == 2 else x
-        x_proj = proj(x)
-        z = self.encoder(x_proj, lengths=enc_lengths)
+    def _critic(self, x, x_proj, z, dec, lengths, use_nce):
+        """Decoder + next-step loss of one modality (models.py:202-215 / 234-244) and the logged `diff_next`."""
         if use_nce and x.shape[1] > 1:
             recon = dec(z)
             mask = None
@@ -221,20 +238,28 @@ class UML(nn.Module):
             loss = self.y_critic(recon[:, :-1, :], x[:, 1:, :], mask=mask[:, 1:] if mask is not None else None)
         else:
             loss, recon = _DecoderNextStepMSE.apply(z, dec.fc.weight, dec.fc.bias, x, lengths)
-        diff_next = (x_proj - z).pow(2).mean()
-        return x, x_proj, z, recon, loss, diff_next
+        return recon, loss, (x_proj - z).pow(2).mean()
 
     def forward(self, x, y, x_lengths=None, y_lengths=None):
         dev = (x if x is not None else y).device
         loss_x = loss_y = torch.zeros((), device=dev)          # a fill kernel: torch.tensor(0.0, device=...) is a blocking host copy
         x_proj = y_proj = zx = zy = x_recon = y_recon = diff_next_x = diff_next_y = None
         if x is not None:
-            x, x_proj, zx, x_recon, loss_x, diff_next_x = self._branch(x, self.xproj_in, self.decoders[0], x_lengths,
-                                                                        x_lengths, False)
+            x = x.unsqueeze(1).float() if x.ndim == 2 else x
+            x_proj = self.xproj_in(x)
         if y is not None:
-            # the reference encodes y WITHOUT a key-padding mask (models.py:233) but masks its loss
-            y, y_proj, zy, y_recon, loss_y, diff_next_y = self._branch(y, self.yproj_in, self.decoders[1], y_lengths,
-                                                                        None, self.infoNCE_loss)
+            y = y.unsqueeze(1).float() if y.ndim == 2 else y
+            y_proj = self.yproj_in(y)
+        # the reference encodes y WITHOUT a key-padding mask (models.py:233) but masks its loss
+        if x is not None and y is not None and hasattr(self.encoder, "forward_pair"):
+            zx, zy = self.encoder.forward_pair(x_proj, x_lengths, y_proj, None)     # both passes, one autograd node
+        else:
+            zx = self.encoder(x_proj, lengths=x_lengths) if x is not None else None
+            zy = self.encoder(y_proj) if y is not None else None
+        if x is not None:
+            x_recon, loss_x, diff_next_x = self._critic(x, x_proj, zx, self.decoders[0], x_lengths, False)
+        if y is not None:
+            y_recon, loss_y, diff_next_y = self._critic(y, y_proj, zy, self.decoders[1], y_lengths, self.infoNCE_loss)
         loss_private = torch.zeros((), device=dev)
         x_private = y_private = None
         if x is not None and y is not None:
