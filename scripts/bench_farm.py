@@ -48,6 +48,7 @@ def main():
     grid["patience"] = [10 ** 6]
     grid["dropout"] = [None] + [0.1 * (k + 1) for k in range(a.replicas - 1)]   # unused by the head: replicates the grid, distinct result dirs
     n_points = len(ft._grid(grid))
+    torch.manual_seed(0)        # (first call: torch.cuda.manual_seed_all -> device_count -> amdsmi_init, a one-time 0.1 s of the process)
     out = []
     for w in [1] + a.workers + (["grouped"] if a.grouped else []):   # the first pass is an untimed warm-up (module load, allocator)
         with tempfile.TemporaryDirectory() as tmp:

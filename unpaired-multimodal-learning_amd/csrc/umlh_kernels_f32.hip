@@ -123,6 +123,11 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
             else xreg[q] = xsrc[q] ? load4_guard(xsrc[q] + k, K - k, vecX) : f32x4v{0.f, 0.f, 0.f, 0.f};
         }
     };
+    // FAST: the LDS tiles are [row][16 k] (row = class / sample, 64 B) with the four 16-B slots of a row XOR-swizzled by
+    // (row >> 2) & 3: the 16-B pieces go to LDS as they come from memory (no transposing scalar stores), and the eight
+    // k-steps of a chunk of one MFMA operand are two ds_read_b128 (lane half h multiplies k = 8h .. 8h+7; the order of k
+    // inside a chunk is free as long as W and X agree) -- 10 LDS reads per 32 MFMAs instead of 40, 9 LDS stores per thread
+    // instead of 36.  The swizzle makes both access patterns conflict-free without padding (same 64 KB per W buffer).
     auto lstore = [&](int buf) {
         float* Ws = Ws0 + buf * BUF;
         float* Xs = Ws + KT * LDW;
@@ -131,8 +136,11 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
             int p = tid + 512 * q;
             if (p < CPAD * 4) {
                 int cls = p >> 2, g = p & 3;
+                if (FAST) *reinterpret_cast<f32x4v*>(&Ws[cls * KT + 4 * (g ^ ((cls >> 2) & 3))]) = wreg[q];
+                else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Ws[(4 * g + j) * LDW + cls] = wreg[q][j];
+                    for (int j = 0; j < 4; ++j) Ws[(4 * g + j) * LDW + cls] = wreg[q][j];
+                }
             }
         }
 #pragma unroll
@@ -140,8 +148,11 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
             int p = tid + 512 * q;
             if (p < TS * 4) {
                 int smp = p >> 2, g = p & 3;
+                if (FAST) *reinterpret_cast<f32x4v*>(&Xs[smp * KT + 4 * (g ^ ((smp >> 2) & 3))]) = xreg[q];
+                else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Xs[(4 * g + j) * LDX + smp] = xreg[q][j];
+                    for (int j = 0; j < 4; ++j) Xs[(4 * g + j) * LDX + smp] = xreg[q][j];
+                }
             }
         }
     };
@@ -155,6 +166,25 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
         const float* Ws = Ws0 + buf * BUF;
         const float* Xs = Ws + KT * LDW;
         if (!wave_live) return;                       // ONE wave-uniform branch per chunk: the MFMA loop itself stays branch-free
+        if (FAST) {
+            const int sw = (l31 >> 2) & 3;            // tile bases are multiples of 32: (row >> 2) & 3 == (l31 >> 2) & 3
+            const float* xr = Xs + (ws * 32 + l31) * KT;
+            f32x4v b[2], av[CTW][2];
+            b[0] = *reinterpret_cast<const f32x4v*>(xr + 4 * ((2 * h) ^ sw));
+            b[1] = *reinterpret_cast<const f32x4v*>(xr + 4 * ((2 * h + 1) ^ sw));
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+                const float* wr = Ws + ((wc * CTW + ct) * 32 + l31) * KT;
+                av[ct][0] = *reinterpret_cast<const f32x4v*>(wr + 4 * ((2 * h) ^ sw));
+                av[ct][1] = *reinterpret_cast<const f32x4v*>(wr + 4 * ((2 * h + 1) ^ sw));
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct][s2 >> 2][s2 & 3], b[s2 >> 2][s2 & 3], acc[ct], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
             const int krow = 2 * kk + h;
