@@ -31,6 +31,7 @@ def run(z, steps=30, B=32, T=50, torch_ref=False):
         from test_encoder_gpu import _torch_reference
         enc = m.encoder
         enc.forward = lambda x, lengths=None: _torch_reference(enc, x, lengths)
+        enc.forward_pair = lambda x, lx, y, ly: (enc.forward(x, lengths=lx), enc.forward(y, lengths=ly))
         for lin in (m.xproj_in, m.yproj_in):
             lin.forward = lin.fc.forward
     opt = build_optimizer(m.parameters(), "adam", 1e-3, 0.0)

@@ -27,4 +27,10 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/${tag}_kt_micro -o kt -- python3 $root/scripts/small_step_timing.py 32 fp32 4 > $root/$o/${tag}_kt_micro.log 2>&1
 cd $root
 python scripts/summarize_rocprof.py $(dirname $(find $o/${tag}_kt_micro -name "kt_kernel_stats.csv" | head -1)) kt $o/${tag}_micro_kernel_stats.md "Command: rocprofv3 --kernel-trace --stats -- python3 scripts/small_step_timing.py 32 fp32 4 (cfg1 shape d=512 C=100, batch 32+32, 4 x 100 steps through umlh_train_steps = 4 persistent launches of 100 steps each)" > /dev/null
+# MultiBench alternation step: step time (z = 40 / 300, HIP encoder vs torch.nn ops) and the kernel trace at z = 40
+python scripts/bench_multibench.py 2>/dev/null > $o/${tag}_multibench_step.txt
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/${tag}_kt_mb -o kt -- python3 $root/scripts/bench_multibench.py 40 100 > $root/$o/${tag}_kt_mb.log 2>&1
+cd $root
+python scripts/summarize_rocprof.py $(dirname $(find $o/${tag}_kt_mb -name "kt_kernel_stats.csv" | head -1)) kt $o/${tag}_multibench_kernel_stats_after.md "Command: rocprofv3 --kernel-trace --stats -- python3 scripts/bench_multibench.py 40 100 (z = 40, T = 50, B = 32, train mode; >= 1 s warm-up + 100 timed steps; 2 multi_opt_kernel launches per step)" > /dev/null
 tail -2 $o/${tag}_bench.json | cut -c1-600

@@ -160,12 +160,17 @@ class _Lease:
         self.plan.busy = False
 
 
-_PLANS = {}
+_PLANS = {}                 # configuration key -> plans (dict order = least recently used first)
 _PLAN_POOL_MAX = 8          # plans kept per configuration (each holds the stack's saved activations: ~0.1 GB at MOSEI sizes)
+_PLAN_KEYS_MAX = 16         # configurations kept: beyond that the least recently used idle ones are dropped
 
 
 def _lease_plan(key, make):
-    pool = _PLANS.setdefault(key, [])
+    pool = _PLANS.pop(key, [])
+    _PLANS[key] = pool                                     # most recently used
+    if len(_PLANS) > _PLAN_KEYS_MAX:
+        for k in [k for k, v in _PLANS.items() if k != key and not any(pl.busy for pl in v)][:len(_PLANS) - _PLAN_KEYS_MAX]:
+            del _PLANS[k]
     for pl in pool:
         if not pl.busy:
             return _Lease(pl)
