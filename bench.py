@@ -170,8 +170,20 @@ def main():
         stepper.broadcast_parameters([model.head.weight.data])
         tab_i, tab_t = img_src.table(precision), txt_src.table(precision)
         engine.bind_tables(tab_i, tab_t)
-        c_level_dp = (world > 1 and not rehearsal and not args.dp_host_loop and stepper.attach_rccl()) or \
-                     (world == 1 and args.force_dp_path and not args.dp_host_loop)
+        c_level_dp = world == 1 and args.force_dp_path and not args.dp_host_loop
+        if world > 1 and not rehearsal and not args.dp_host_loop:
+            # every rank must take the same loop: a rank whose communicator could not be created (library missing, init
+            # error) sends the whole job to the per-step torch.distributed path instead of leaving the others in a collective
+            try:
+                ok = 1 if stepper.attach_rccl() else 0
+            except umlh.UmlhError as exc:
+                print(f"[rank {rank}] C-level RCCL loop unavailable ({exc}); falling back to per-step torch.distributed", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            c_level_dp = bool(int(flag.item()))
+            if ok and not c_level_dp:
+                engine.detach_comm()
 
         def slot(m):
             if cursor["k"] + m > ring:
@@ -219,8 +231,21 @@ def main():
                 done += m
             return rows
 
+        watchdog = None
+        if world > 1:
+            # a collective that never completes (a rank missing from the communicator) would otherwise hold the job until
+            # the caller's own limit: fail fast and say where
+            import threading
+            watchdog = threading.Timer(180.0, lambda: (print(f"[rank {rank}] data-parallel warm-up did not finish in 180 s "
+                                                                 f"({'C-level RCCL loop' if c_level_dp else 'per-step torch.distributed'}); aborting",
+                                                                 file=sys.stderr, flush=True), os._exit(4)))
+            watchdog.daemon = True
+            watchdog.start()
         run_steps(prime)
         run_steps(warmup)
+        if watchdog is not None:
+            fence()
+            watchdog.cancel()
         blocks, enq = [], []
         for _ in range(repeats):
             fence()

@@ -325,6 +325,11 @@ class HeadEngine:
         check(self.lib.umlh_comm_init_rank(self.handle, idb, world, rank), "umlh_comm_init_rank")
         return True
 
+    def detach_comm(self) -> None:
+        """Drop the communicator (``umlh_set_comm(h, NULL, 1)``): ``train_steps`` is single-GPU again and the data-parallel
+        step goes through ``grad_step`` / ``apply_update`` with the caller's all-reduce."""
+        check(self.lib.umlh_set_comm(self.handle, None, 1), "umlh_set_comm")
+
     def set_allreduce(self, fn, n_ranks: int) -> None:
         """Custom transport for the C-level data-parallel loop (``umlh_set_allreduce``): ``fn(tensor)`` must SUM-all-reduce
         the given fp32 view of the gradient message in place, ordered with the current stream (tests: gloo).  ``fn=None``
