@@ -303,3 +303,23 @@ def test_eval_rows_per_row_stats(precision):
         loss = np.mean([st[s:s + bs, 0].mean() for s in range(0, n, bs)])
         ol, oa = O.validate(O.HeadState(w, None, 30.0, 30.0, False), x, y, bs, rng_draw=False)
         assert abs(loss - ol) < 1e-4 and abs(st[:, 1].mean() - oa) < 1e-6
+
+
+def test_gradient_diagnostics_are_bitwise_reproducible():
+    """The per-modality gradient diagnostics (finetune.py:190-191,203-206) are reduced in a fixed order (per-workgroup
+    partials, summed by the workgroup that takes the last ticket): the same step from the same state gives bit-identical
+    dot / norms / agreement, whatever order the workgroups finished in.  C x d = 512 000 elements = 500 workgroups."""
+    rng = np.random.default_rng(21)
+    st, xi, yi, xt, yt, ii, ti = _random_case(rng, 512, 512, 1000, 600, 600, 256, 256, False, False, 100.0)
+    rows = []
+    for rep in range(6):
+        e = _engine(st, wd=0.01, max_img=256, max_txt=256)
+        e.enable_diagnostics(True)
+        out = torch.zeros(12, dtype=torch.float32, device=DEV)
+        for k in range(2):
+            e.train_step(_rb(xi, yi, ii), _rb(xt, yt, ti), lr=1e-3, step=k + 1, alpha=0.7, scalars_out=out)
+        torch.cuda.synchronize()
+        rows.append(out.cpu().numpy().copy())
+    assert np.isfinite(rows[0]).all() and abs(rows[0][8:]).sum() > 0
+    for r in rows[1:]:
+        assert np.array_equal(r, rows[0])

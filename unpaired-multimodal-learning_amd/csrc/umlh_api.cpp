@@ -70,7 +70,7 @@ static int fail(int code, const char* fmt, ...) {
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 struct Layout {                 // workspace partition, in floats from the base
-    long long dzt, h, dht, slabs_head, slabs_proj, partials, grads, w16, iota, zeros, dbg, wpt16, wht16, total;
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, diag_part, grads, w16, iota, zeros, dbg, wpt16, wht16, total;
     long long mc_flags, mc_xchg, mc_ext, mc_tab, mc_desc;   // micro-step region (umlh_kernels_micro.hip); mc_flags = 0: unsupported shape
     int mc_nwg, mc_nch, mc_cw;
     long long n_iota;
@@ -145,6 +145,7 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     L.slabs_head = take((long long)L.scap_head * L.n_head);
     L.slabs_proj = take((long long)L.scap_proj * L.n_proj);
     L.partials = take((long long)L.max_blocks * 4);
+    L.diag_part = take(4 * ((L.n_head + 1023) / 1024 + 2) + 64);     // gradient diagnostics: [head_step blocks][4] partials, then the ticket
     L.grads = take(2 * L.n_head + L.n_proj + 2 + UMLH_N_SCALARS);    // 2 x n_head: the data-parallel message carries the image and
                                                                      // the text gradient separately when diagnostics are on
     L.w16 = take(c.precision == UMLH_PREC_BF16 ? 1024LL * c.d_shared / 2 : 0);   // bf16 chunk-major shadow of w_head (<= 1024 class rows)
@@ -183,7 +184,7 @@ struct umlh_handle_s {
     int last_rows_img, last_rows_txt;
     bool iota_ready;            // bf16: identity row-id table in the workspace initialised
     bool shadow_fresh;          // bf16: the W shadow was written by the previous step's update kernel
-    float* diag_dst;            // this step's 4 gradient-diagnostic accumulators (zeroed by the forward kernel)
+    float* diag_dst;            // where this step's 4 gradient diagnostics go (written by the head-step launch)
     int n_slabs_img;            // dW_head slabs that hold image rows (the rest hold text rows)
     bool diagnostics;           // umlh_enable_diagnostics
     float* row_stats;           // per-row {CE, correct} output of the next forward (umlh_eval_rows), else NULL
@@ -365,6 +366,11 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
     h->bound = true;
     h->iota_ready = false;
     h->shadow_fresh = false;
+    {                             // ticket of the gradient-diagnostics reduction (head_step_kernel leaves it at 0 after every launch)
+        DeviceGuard dg_(h->device);
+        const long long np = 4 * ((h->L.n_head + 1023) / 1024 + 2);
+        if (hipMemset(ws(h, h->L.diag_part) + np, 0, 64 * sizeof(float)) != hipSuccess) return fail(UMLH_E_HIP, "umlh_bind: clearing the diagnostics ticket failed");
+    }
     if (h->L.mc_flags) {          // epoch flags, status word and exchange records start from zero (bind time only)
         DeviceGuard dg_(h->device);
         const size_t n = (size_t)(h->L.mc_tab - h->L.mc_flags) * sizeof(float);
@@ -874,7 +880,6 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         fb.partials = ws(h, L.partials);
         fb.dbg = h->dbg_fwd;
         fb.learn = c.learnable_temp;
-        fb.diag_zero = h->diag_dst;
         fb.row_stats = h->row_stats;
         fb.stamps = fb.dbg == 9 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
@@ -963,7 +968,6 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     fa.W = h->buf.w_head; fa.C = c.num_classes; fa.K = c.d_shared;
     fa.dzt = want_grad ? dzt : nullptr; fa.ldz = L.ldz;
     fa.partials = ws(h, L.partials);
-    fa.diag_zero = h->diag_dst;
     fa.row_stats = h->row_stats;
     HIPCHK(umlh_f32_launch_fwd(&fa, h->ctw, h->wc, nb0 + nb1, st), "fwd_ce");
     mark(h, 2, st);
@@ -1069,8 +1073,7 @@ static int check_step(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch
 static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_batch_t* txt, const umlh_hyper_t* hy,
                            float* scalars_out, hipStream_t st, bool keep_shadow) {
     int sh = 0, sp = 0;
-    // gradient diagnostics: accumulators in the caller's scalar row (or the workspace tail), zeroed by the
-    // forward kernel, added to by the head-step blocks
+    // gradient diagnostics: written to the caller's scalar row (or the workspace tail) by the head-step launch
     h->dp_diag = false;
     float* tail = ws(h, h->L.grads) + msg_tail_off(h);
     h->diag_dst = h->diagnostics ? (scalars_out ? scalars_out : tail + 2) + UMLH_N_CORE_SCALARS : nullptr;
@@ -1081,6 +1084,8 @@ static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_
     const umlh_config_t& c = h->cfg;
     DiagArgs dg;
     dg.dst = h->diag_dst; dg.n_slabs_img = h->n_slabs_img;
+    dg.part = ws(h, h->L.diag_part);
+    dg.ticket = reinterpret_cast<unsigned*>(dg.part + 4 * ((h->L.n_head + 1023) / 1024 + 2));
     dg.inv_w0 = hy->img_alpha != 0.f ? 1.f / hy->img_alpha : 0.f;
     dg.inv_w1 = hy->alpha != 0.f ? 1.f / hy->alpha : 0.f;
     if (c.d_shared % 8 == 0) {
@@ -1490,7 +1495,7 @@ static int dp_reduce_head(umlh_handle_t h, const umlh_batch_t* img, const umlh_b
         const int si = h->n_slabs_img < sh ? h->n_slabs_img : sh;
         FinalizeArgs f2 = f;
         f2.partials = nullptr;                           // the step scalars are formed once (first launch)
-        DiagArgs none; none.dst = nullptr; none.n_slabs_img = si; none.inv_w0 = none.inv_w1 = 0.f;
+        DiagArgs none; none.dst = nullptr; none.n_slabs_img = si; none.inv_w0 = none.inv_w1 = 0.f; none.part = nullptr; none.ticket = nullptr;
         if (si > 0) HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), si, nh, h->cfg.num_classes, h->cfg.d_shared, nullptr, nullptr,
                                                  nullptr, &o, nullptr, 32 * h->ctw * h->wc, &f, grads, &none, st), "reduce head (image rows)");
         else HIPCHK((int)hipMemsetAsync(grads, 0, sizeof(float) * nh, st), "zero image gradient");
@@ -1603,11 +1608,12 @@ static int apply_update_impl(umlh_handle_t h, const umlh_hyper_t* hy, float* sca
         const bool bf = h->cfg.precision == UMLH_PREC_BF16;
         DiagArgs dg;
         dg.dst = nullptr; dg.n_slabs_img = 1; dg.inv_w0 = dg.inv_w1 = 0.f;
+        dg.part = ws(h, h->L.diag_part);
+        dg.ticket = reinterpret_cast<unsigned*>(dg.part + 4 * ((h->L.n_head + 1023) / 1024 + 2));
         if (h->dp_diag) {
             // the two all-reduced per-modality gradients are the two "slabs" of the update kernel: it sums them, steps the
             // weights and accumulates dot / norms / sign agreement of the GLOBAL gradients (finetune.py:203-206)
             float* dst = (scalars_out ? scalars_out : f.tail + 2) + UMLH_N_CORE_SCALARS;
-            HIPCHK((int)hipMemsetAsync(dst, 0, sizeof(float) * (UMLH_N_SCALARS - UMLH_N_CORE_SCALARS), st), "zero diagnostics");
             dg.dst = dst;
             dg.inv_w0 = hy->img_alpha != 0.f ? 1.f / hy->img_alpha : 0.f;
             dg.inv_w1 = hy->alpha != 0.f ? 1.f / hy->alpha : 0.f;

@@ -37,7 +37,6 @@ struct FwdArgs {
     float* dzt;                  // [C, ldz] dZ^T (class-major), NULL = eval (no gradient)
     int   ldz;
     float* partials;             // [grid][4] = {loss_sum, correct, gscale_sum, 0}
-    float* diag_zero;            // 4 floats zeroed by block 0 (gradient-diagnostic accumulators of this step), or NULL
     float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
 };
 
@@ -121,7 +120,6 @@ struct FwdArgsB {
     int   dbg;                   // 9 = cycle stamps; other values: timing-only ablations (analysis build -DUMLH_ABLATIONS only)
     int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
     unsigned long long* stamps;  // diagnostic build only (UMLH_DBG_FWD=9): [grid][8] s_memtime stamps of wave 0
-    float* diag_zero;            // 4 floats zeroed by block 0 (gradient-diagnostic accumulators of this step), or NULL
     float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
 };
 
@@ -176,10 +174,12 @@ struct FinalizeArgs {
 
 // gradient diagnostics of one step, by-products of the slab reduction (head_step_kernel)
 struct DiagArgs {
-    float* dst;                  // 4 accumulators {dot, |g_img|^2, |g_txt|^2, sign agreements}, zeroed by the forward; NULL = off
+    float* dst;                  // {dot, |g_img|^2, |g_txt|^2, sign agreements} of the step; NULL = off
     int   n_slabs_img;           // slabs [0, n_slabs_img) hold the image rows' partial sums
     float inv_w0, inv_w1;        // 1 / loss weight of each modality (0 if the weight is 0)
-};
+    float* part;                 // [blocks][4] per-workgroup partial sums; the workgroup that takes the LAST ticket adds them
+    unsigned* ticket;            // in a fixed order (lane l: blocks l, l+64, ...; then a fixed lane tree) -> dst: the values do
+};                               // not depend on the order the workgroups finished in.  ticket is 0 between launches.
 
 // torch.optim single-tensor update of one element (see oracle/uml_oracle.py
 // optimizer_step for the restated recurrence and its reference citations).

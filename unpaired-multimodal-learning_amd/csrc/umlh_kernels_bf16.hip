@@ -513,7 +513,6 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 #pragma unroll
         for (int w = 0; w < WS; ++w) { l += red2[w * 4 + 0]; c += red2[w * 4 + 1]; g += red2[w * 4 + 2]; }
         float* o = a.partials + (size_t)blockIdx.x * 4;
-        if (blockIdx.x == 0 && a.diag_zero != nullptr) { a.diag_zero[0] = a.diag_zero[1] = a.diag_zero[2] = a.diag_zero[3] = 0.f; }
         o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
     }
     STAMP(5);

@@ -319,7 +319,6 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
 #pragma unroll
         for (int w = 0; w < WS; ++w) { l += red2[w * 4 + 0]; c += red2[w * 4 + 1]; g += red2[w * 4 + 2]; }
         float* o = a.partials + (size_t)blockIdx.x * 4;
-        if (blockIdx.x == 0 && a.diag_zero != nullptr) { a.diag_zero[0] = a.diag_zero[1] = a.diag_zero[2] = a.diag_zero[3] = 0.f; }
         o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
     }
 }
@@ -1037,9 +1036,24 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
         const int w = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) { sh[0][w] = dot; sh[1][w] = n2i; sh[2][w] = n2t; sh[3][w] = agree; }
         __syncthreads();
+        const int nblk = (int)gridDim.x - 1;                 // (the last block of the grid is the finalize block)
         if (threadIdx.x < 4) {
             const float t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
-            __hip_atomic_fetch_add(dg.dst + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dg.part + (size_t)blockIdx.x * 4 + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            sh[4][0] = __hip_atomic_fetch_add(dg.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1) ? 1.f : 0.f;
+        __syncthreads();
+        if (sh[4][0] != 0.f) {                               // last ticket: every workgroup's partials are published
+            const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+            float t = 0.f;
+            for (int b = l; b < nblk; b += 64) t += __hip_atomic_load(dg.part + (size_t)b * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if (l == 0) dg.dst[q] = t;
+            if (threadIdx.x == 0) __hip_atomic_store(dg.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (!live) return;
@@ -1295,7 +1309,8 @@ int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride
     long long n4 = (long long)C * K / 4;
     int blocks = (int)((n4 + 255) / 256) + 1;                 // + the finalize block
     DiagArgs d;
-    if (dg) d = *dg; else { d.dst = nullptr; d.n_slabs_img = n_slabs; d.inv_w0 = d.inv_w1 = 0.f; }
+    if (dg) d = *dg; else { d.dst = nullptr; d.n_slabs_img = n_slabs; d.inv_w0 = d.inv_w1 = 0.f; d.part = nullptr; d.ticket = nullptr; }
+    if (d.dst && (!d.part || !d.ticket)) return (int)hipErrorInvalidValue;
     if (d.n_slabs_img > n_slabs) d.n_slabs_img = n_slabs;
     hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, *o,
                        (unsigned short*)shadow, cpad, *f, grad_out, d);
