@@ -21,8 +21,11 @@ python scripts/make_pmc_json.py $(find $o/${tag}_pmc_f -name "*counter_collectio
 python scripts/micro_stamps.py 512 100 32 4096 > $o/${tag}_micro_stamps.txt 2>&1
 python scripts/small_step_timing.py 32 fp32 4 > $o/${tag}_micro_step_timing.txt 2>&1
 UMLH_MICRO=0 python scripts/small_step_timing.py 32 fp32 4 >> $o/${tag}_micro_step_timing.txt 2>&1
+python scripts/small_step_timing.py 32 bf16 4 >> $o/${tag}_micro_step_timing.txt 2>&1
+UMLH_MICRO=0 python scripts/small_step_timing.py 32 bf16 4 >> $o/${tag}_micro_step_timing.txt 2>&1
 python scripts/bench_farm.py --iters 1000 --workers 1 --grouped > $o/${tag}_farm.txt 2>&1
 python scripts/bench_farm.py --iters 4000 --workers 1 --grouped >> $o/${tag}_farm.txt 2>&1
+python scripts/bench_farm.py --iters 4000 --workers 1 --grouped --precision bf16 >> $o/${tag}_farm.txt 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/${tag}_kt_micro -o kt -- python3 $root/scripts/small_step_timing.py 32 fp32 4 > $root/$o/${tag}_kt_micro.log 2>&1
 cd $root

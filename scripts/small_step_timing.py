@@ -15,6 +15,7 @@ x16 = umlh.to_bf16(x)
 e = umlh.HeadEngine(d, d, C, optimizer="adamw", weight_decay=0.01, max_rows_img=B, max_rows_txt=B, precision=prec, device=DEV)
 e.w_head.normal_(0, 0.05); e.scales.fill_(100.0)
 n = 100
+print(f"# cfg1 shape d={d} C={C} batch {B}+{B}, precision {prec}, UMLH_MICRO={os.environ.get('UMLH_MICRO', '1')} (micro launches so far: see the last line)")
 tab = (x, y, x16) if prec == "bf16" else (x, y)
 for rep in range(int(sys.argv[3]) if len(sys.argv) > 3 else 4):
     bi = [torch.randint(0, 4096, (B,), generator=g, device=DEV) for _ in range(n)]
@@ -29,3 +30,4 @@ for rep in range(int(sys.argv[3]) if len(sys.argv) > 3 else 4):
     w = e.w_head.detach().cpu().clone()
     t3 = time.perf_counter()
     print(f"rep {rep}: enqueue {1e6 * (t1 - t0) / n:7.1f} us/step   drain {1e6 * (t2 - t1) / n:7.1f} us/step   total {1e6 * (t2 - t0) / n:7.1f} us/step   state copy {1e3 * (t3 - t2):.2f} ms")
+print(f"# micro launches: {e.micro_launches()}")

@@ -213,3 +213,43 @@ def test_train_replays_reference_run_on_the_micro_path(tag):
     assert out["iter"] == int(g["best_iter"]) and abs(out["val_acc"] - float(g["best_val_acc"])) < 1e-6
     np.testing.assert_allclose(out["model"]["head.weight"].numpy(), g["w_head_best"], atol=1e-5, rtol=1e-4)
     assert abs(test_acc - float(g["test_acc"])) <= 1e-3 and abs(test_loss - float(g["test_loss"])) < 1e-4
+
+
+@pytest.mark.parametrize("d,C,ri,rt", [(512, 100, 32, 32), (768, 1000, 32, 24), (1024, 47, 16, 48), (128, 10, 64, 0)])
+def test_micro_steps_bf16_operand_mode(d, C, ri, rt, monkeypatch):
+    """bf16 engines take the micro path too (operands rounded to bf16 at use, fp32 accumulation, fp32 master weights): the
+    per-step losses follow the general bf16 path (three kernels, bf16 shadows) within the precision mode's own noise and the
+    fp32 path loosely; accuracies and the final weights agree."""
+    import umlh
+    rng = np.random.default_rng(d + C)
+    n_img, n_txt, steps = 300, 260, 10
+    xi, yi, xt, yt = _tables(rng, d, C, n_img, n_txt)
+    w0 = rng.standard_normal((C, d)).astype(np.float32)
+    w0 /= np.linalg.norm(w0, axis=1, keepdims=True)
+    bi = [rng.permutation(n_img)[:ri] for _ in range(steps)] if ri else None
+    bt = [rng.permutation(n_txt)[:rt] for _ in range(steps)] if rt else None
+    lrs = [1e-3] * steps
+
+    def run(micro, precision):
+        monkeypatch.setenv("UMLH_MICRO", "1" if micro else "0")
+        e = umlh.HeadEngine(d, d, C, optimizer="adamw", weight_decay=0.01, max_rows_img=64, max_rows_txt=64, precision=precision, device=DEV)
+        e.w_head.copy_(_T(w0)); e.scales.fill_(30.0)
+        sc = torch.zeros(steps, umlh.N_SCALARS, device=DEV)
+        tab = lambda x, y: (_T(x), _T(y, torch.int64)) + ((umlh.to_bf16(_T(x)),) if precision == "bf16" else ())
+        e.train_steps(tab(xi, yi) if ri else None, [_T(b, torch.int64) for b in bi] if ri else None,
+                      tab(xt, yt) if rt else None, [_T(b, torch.int64) for b in bt] if rt else None, lrs, first_step=1, alpha=0.7, scalars_out=sc)
+        torch.cuda.synchronize()
+        assert e.micro_status() == 0 and (e.micro_launches() > 0) == micro
+        return e.w_head.cpu().numpy(), sc.cpu().numpy()
+    wm, sm = run(True, "bf16")
+    wg, sg = run(False, "bf16")
+    wf, sf = run(True, "fp32")
+    cols = [c for c, live in ((umlh.S_LOSS_IMG, ri), (umlh.S_LOSS_TXT, rt)) if live]
+    np.testing.assert_allclose(sm[:, cols], sg[:, cols], atol=3e-3, rtol=2e-3)          # two bf16 implementations
+    np.testing.assert_allclose(sm[:, cols], sf[:, cols], atol=2e-2, rtol=1e-2)          # bf16 operands vs fp32
+    acc = [c for c, live in ((umlh.S_ACC_IMG, ri), (umlh.S_ACC_TXT, rt)) if live]
+    assert np.abs(sm[:, acc] - sg[:, acc]).max() <= 2.0 / 16 + 1e-6                     # at most a couple of near-tie rows flip
+    lim = 2 * sum(lrs) + 1e-6
+    for ref in (wg, wf):
+        diff = np.abs(wm - ref)
+        assert diff.max() <= lim and (diff > 2e-4 + 1e-3 * np.abs(ref)).mean() < 0.05

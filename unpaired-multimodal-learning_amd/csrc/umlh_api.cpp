@@ -16,7 +16,8 @@
 
 extern "C" {
 int umlh_micro_chunking(int d, int* nch, int* cw);
-int umlh_micro_launch(int nch, int cw, const UmlhMicroHead* heads, int n_heads, int n_steps, int grid, hipStream_t st);
+int umlh_micro_launch(int nch, int cw, int bf16, const UmlhMicroHead* heads, int n_heads, int n_steps, int grid, hipStream_t st);
+int umlh_micro_bf16_supported(int nch, int cw);
 int umlh_f32_fwd_config(int C, int* ctw, int* wc);
 int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t stream);
 int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream);
@@ -158,11 +159,12 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     const bool bfp = c.precision == UMLH_PREC_BF16 && c.has_proj;
     L.wpt16 = take(bfp ? (L.n_proj + 1) / 2 : 0);         // bf16 W_proj^T [d_img][d_shared]
     L.wht16 = take(bfp ? 1024LL * round_up(c.d_shared, 128) / 2 : 0);   // bf16 W_head^T by class chunks [16][d_shared^128][64]
-    // micro-step path: fp32 linear head whose width has a supported chunking
+    // micro-step path: linear head whose width has a supported chunking (bf16 operand mode: widths that are multiples of 128)
     L.mc_flags = L.mc_xchg = L.mc_ext = L.mc_tab = L.mc_desc = 0;
     L.mc_nwg = (c.num_classes + UMLH_MICRO_CS - 1) / UMLH_MICRO_CS;
     L.mc_nch = L.mc_cw = 0;
-    if (c.precision == UMLH_PREC_FP32 && !c.has_proj && umlh_micro_chunking(c.d_shared, &L.mc_nch, &L.mc_cw)) {
+    if (!c.has_proj && umlh_micro_chunking(c.d_shared, &L.mc_nch, &L.mc_cw) &&
+        (c.precision == UMLH_PREC_FP32 || umlh_micro_bf16_supported(L.mc_nch, L.mc_cw))) {
         L.mc_flags = take(64 + 64);                                              // [nwg <= 64] epoch flags, then the status word
         L.mc_xchg = take(2LL * L.mc_nwg * 5 * UMLH_MICRO_MAX_ROWS * 2);       // 8-byte granules
         L.mc_ext = 0;
@@ -1232,7 +1234,7 @@ static int micro_launch_group(const MicroItem* it, int n, int k0, int n_steps, h
         } else {
             HIPCHK((int)hipStreamWaitEvent(st, g_micro_ev[dv], 0), "micro step: chain wait");
         }
-        HIPCHK(umlh_micro_launch(h0->L.mc_nch, h0->L.mc_cw, ddesc, n, n_steps, grid, st), "micro_steps_kernel");
+        HIPCHK(umlh_micro_launch(h0->L.mc_nch, h0->L.mc_cw, h0->cfg.precision == UMLH_PREC_BF16, ddesc, n, n_steps, grid, st), "micro_steps_kernel");
         HIPCHK((int)hipEventRecord(g_micro_ev[dv], st), "micro step: chain record");
     }
     return UMLH_OK;
@@ -1247,7 +1249,7 @@ static int micro_run(const MicroItem* it, int n_items, int n_steps, hipStream_t 
         while (a < n_items) {
             int b = a, wgs = 0;
             while (b < n_items && b - a < UMLH_MICRO_MAX_HEADS && wgs + it[b].h->L.mc_nwg <= cus &&
-                   it[b].h->cfg.d_shared == it[a].h->cfg.d_shared) {
+                   it[b].h->cfg.d_shared == it[a].h->cfg.d_shared && it[b].h->cfg.precision == it[a].h->cfg.precision) {
                 wgs += it[b].h->L.mc_nwg;
                 ++b;
             }

@@ -92,6 +92,20 @@ __device__ __forceinline__ void rows_argmax(float& m, int& am) {      // max, ti
     m = t1 ? m1 : m0; am = t1 ? i1 : i0;
 }
 
+// bf16 operand mode (BASELINE config "linear head bf16"; the precision mode of the general bf16 path: operands rounded
+// to bf16 at use, fp32 accumulation, fp32 master weights and optimizer): the SAME fragments the fp32 MFMAs consume one float
+// at a time -- lane (s16, g) holds 4 consecutive k of its row -- are exactly one v_mfma_f32_16x16x16_bf16 operand after two
+// v_cvt_pk_bf16_f32, so a group of four fp32 MFMAs (128 matrix-pipe cycles) becomes one bf16 MFMA (16-32 cycles).
+typedef short s16x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4m pack_bf16x4(float a, float b, float c, float d) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 w = {__builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2)),
+                  __builtin_bit_cast(unsigned, __builtin_convertvector(f2{c, d}, bf2))};
+    return __builtin_bit_cast(s16x4m, w);
+}
+
 template <int NCH, int CW>
 struct MicroCfg {
     static constexpr int D = NCH * CW;
@@ -107,7 +121,7 @@ struct MicroCfg {
     static constexpr int NP = 2 * NCH;                      // chunk positions of a step: NCH forward, NCH backward
 };
 
-template <int NCH, int CW>
+template <int NCH, int CW, bool BF>
 __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* __restrict__ heads, int n_heads, int n_steps) {
     using K = MicroCfg<NCH, CW>;
     constexpr int D = K::D, LDW = K::LDW, SM = K::SM, DPW = K::DPW, U = K::U, NP = K::NP;
@@ -312,10 +326,17 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
                     if (t + 2 < T) ld(t + 2, (t + 2) % 3);
                     __builtin_amdgcn_sched_barrier(0);
                     const int sl = t % 3;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][0], b4[sl][0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][1], b4[sl][1], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][2], b4[sl][2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][3], b4[sl][3], acc1, 0, 0, 0);
+                    if (BF) {                               // k = 16t + 4g + e for element e of lane group g, in both operands
+                        const s16x4m pa = pack_bf16x4(a4[sl][0], a4[sl][1], a4[sl][2], a4[sl][3]);
+                        const s16x4m pb = pack_bf16x4(b4[sl][0], b4[sl][1], b4[sl][2], b4[sl][3]);
+                        if (t & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pb, acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pb, acc0, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][0], b4[sl][0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][1], b4[sl][1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][2], b4[sl][2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sl][3], b4[sl][3], acc1, 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -538,10 +559,21 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             float pw[U][4];
             w_read(c, pw);
             __builtin_amdgcn_sched_barrier(0);              // reads stay ahead of the MFMA chains
+            if (BF) {                                       // rows 16mm + 4e + g for element e of lane group g, in both operands
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
+                for (int mm = 0; mm < 4; ++mm) {
+                    const s16x4m pa = pack_bf16x4(af[4 * mm], af[4 * mm + 1], af[4 * mm + 2], af[4 * mm + 3]);
 #pragma unroll
-                for (int u = 0; u < U; ++u) dacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bq[m][u], dacc[u], 0, 0, 0);
+                    for (int u = 0; u < U; ++u)
+                        dacc[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pack_bf16x4(bq[4 * mm][u], bq[4 * mm + 1][u], bq[4 * mm + 2][u], bq[4 * mm + 3][u]),
+                                                                            dacc[u], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) dacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bq[m][u], dacc[u], 0, 0, 0);
+            }
             // The update reads the accumulators right behind the last MFMA of the chain.  hipcc (ROCm 7.2) pads that read
             // with `s_nop 8`; on gfx950 v_mfma_f32_16x16x4_f32 has a 40-cycle result latency and the LAST accumulator
             // register came back without the final k-step's contribution (rows 60..63 of the batch missing from every
@@ -607,19 +639,19 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
     }
 }
 
-template <int NCH, int CW>
+template <int NCH, int CW, bool BF>
 int launch_one(const UmlhMicroHead* heads, int n_heads, int n_steps, int grid, hipStream_t st) {
     using K = MicroCfg<NCH, CW>;
     static unsigned long long attr_done = 0;               // bit d: done on device d
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_done >> (dev & 63)) & 1ULL)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&micro_steps_kernel<NCH, CW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&micro_steps_kernel<NCH, CW, BF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
         if (e != hipSuccess) return (int)e;
         attr_done |= 1ULL << (dev & 63);
     }
-    hipLaunchKernelGGL((micro_steps_kernel<NCH, CW>), dim3(grid), dim3(256), K::SMEM, st, heads, n_heads, n_steps);
+    hipLaunchKernelGGL((micro_steps_kernel<NCH, CW, BF>), dim3(grid), dim3(256), K::SMEM, st, heads, n_heads, n_steps);
     return (int)hipGetLastError();
 }
 
@@ -636,8 +668,16 @@ int umlh_micro_chunking(int d, int* nch, int* cw) {
     return 0;
 }
 
-#define MICRO_CASE(N_, W_) if (nch == N_ && cw == W_) return launch_one<N_, W_>(heads, n_heads, n_steps, grid, st);
-int umlh_micro_launch(int nch, int cw, const UmlhMicroHead* heads, int n_heads, int n_steps, int grid, hipStream_t st) {
+// bf16 operand mode: widths that are multiples of 128 (the general bf16 path's own requirement)
+int umlh_micro_bf16_supported(int nch, int cw) { return cw == 128 && nch >= 1 && nch <= 8 && nch != 7; }
+
+#define MICRO_CASE(N_, W_) if (nch == N_ && cw == W_) return launch_one<N_, W_, false>(heads, n_heads, n_steps, grid, st);
+#define MICRO_CASE_BF(N_) if (nch == N_ && cw == 128) return launch_one<N_, 128, true>(heads, n_heads, n_steps, grid, st);
+int umlh_micro_launch(int nch, int cw, int bf16, const UmlhMicroHead* heads, int n_heads, int n_steps, int grid, hipStream_t st) {
+    if (bf16) {
+        MICRO_CASE_BF(1) MICRO_CASE_BF(2) MICRO_CASE_BF(3) MICRO_CASE_BF(4) MICRO_CASE_BF(5) MICRO_CASE_BF(6) MICRO_CASE_BF(8)
+        return (int)hipErrorInvalidValue;
+    }
     MICRO_CASE(1, 16) MICRO_CASE(1, 32) MICRO_CASE(3, 16) MICRO_CASE(1, 64) MICRO_CASE(5, 16) MICRO_CASE(3, 32)
     MICRO_CASE(1, 128) MICRO_CASE(2, 128) MICRO_CASE(3, 128) MICRO_CASE(4, 128) MICRO_CASE(5, 128) MICRO_CASE(6, 128)
     MICRO_CASE(8, 128)
