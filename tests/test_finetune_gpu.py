@@ -268,3 +268,41 @@ def test_logger_receives_reference_diagnostics(tag):
         fim, ftm = fi.mean(0), g["x_txt"][bt_all[k]].mean(0)
         ref = float(fim @ ftm / (np.linalg.norm(fim) * np.linalg.norm(ftm)))
         assert abs(steps[k]["train/feature_direction_sim"] - ref) < 1e-4, k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_loop_with_bias_head(precision, monkeypatch):
+    """finetune.train() end to end with a bias=True head (head.py:65,68,122): the single-launch micro path (d = 512 packs
+    to a 640-wide head) and the general three-kernel path train the same model (same batches, per-step losses within the
+    arithmetic's noise), the returned best state carries head.weight AND head.bias, and the padding columns stay zero."""
+    import finetune as ft
+    from engine.datasets.utils import TextTensorDataset
+    from engine.models.head import UMLClip
+    g = torch.Generator().manual_seed(5)
+    C, d = 12, 512
+    proto = torch.nn.functional.normalize(torch.randn(C, d, generator=g), dim=1)
+
+    def draw(n):
+        y = torch.randint(0, C, (n,), generator=g)
+        return torch.nn.functional.normalize(proto[y] + 0.08 * torch.randn(n, d, generator=g), dim=1), y
+    tr, va, te, (xt, yt) = draw(192), draw(200), draw(300), draw(120)
+    text_ds = TextTensorDataset(xt, yt, torch.zeros(len(yt), dtype=torch.long))
+    hp = {"optim": "adamw", "lr": 1e-3, "weight_decay": 0.01, "lr_scheduler": "cosine", "batch_size": 16, "max_iter": 150,
+          "warmup_iter": 10, "warmup_type": "linear", "warmup_min_lr": 1e-5, "patience": 5, "dropout": None, "learnable_temp": False}
+    outs = []
+    for micro in ("1", "0"):
+        monkeypatch.setenv("UMLH_MICRO", micro)
+        gen = torch.Generator()
+        gen.manual_seed(11)
+        torch.manual_seed(11)
+        model = UMLClip(d, C, logit_scale_init=4.60517, bias=True)
+        out = ft.setup_feature_run(tr, va, te, text_ds, hp, num_classes=C, use_clip=True, device=DEV, generator=gen, model=model,
+                                   precision=precision)
+        assert set(out["model"]) == {"head.weight", "head.bias"} and tuple(out["model"]["head.bias"].shape) == (C,)
+        assert out["val_acc"] > 0.9 and float(out["model"]["head.bias"].abs().max()) > 0
+        assert float(model._packed[:, d + 1:].abs().max()) == 0.0
+        outs.append(out)
+    a, b = outs
+    assert a["iter"] == b["iter"] and abs(a["val_acc"] - b["val_acc"]) <= 0.01
+    tol = 2e-4 if precision == "fp32" else 2e-2
+    np.testing.assert_allclose(a["train_scalars"][:, :2].numpy(), b["train_scalars"][:, :2].numpy(), atol=tol, rtol=tol)

@@ -323,3 +323,55 @@ def test_gradient_diagnostics_are_bitwise_reproducible():
     assert np.isfinite(rows[0]).all() and abs(rows[0][8:]).sum() > 0
     for r in rows[1:]:
         assert np.array_equal(r, rows[0])
+
+
+@pytest.mark.parametrize("tag,kind", [("clip_d64_c10_adamw", "clip"), ("uml_d96_c37_sgd", "uml"), ("clip_d512_c100_adam", "clip")])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_head_with_bias_matches_reference(tag, kind, precision):
+    """bias=True heads (engine/models/head.py:65,68,122) against the reference's own classes, autograd and optimizers
+    (tests/golden/bias_heads.npz, oracle/make_golden_bias.py): logits x W^T + b (1e-4 in fp32), per-step losses of a
+    6-8 step trajectory through build_optimizer / build_lr_scheduler, final weight and bias.  The kernels run the bias as
+    column d of a packed [weight | bias | padding] head over rows [x | 1 | 0...]."""
+    import umlh
+    from engine.models.head import UML, UMLClip
+    from engine.optimizer.optim import build_optimizer
+    from engine.optimizer.scheduler import build_lr_scheduler
+    g = load_golden("bias_heads")
+    d, C, Bi, Bt, steps, alpha, wd, oid = g[f"{tag}::cfg"]
+    d, C, steps = int(d), int(C), int(steps)
+    optim = {2: "adamw", 1: "adam", 0: "sgd"}[int(oid)]
+    if precision == "bf16" and optim == "sgd":
+        pytest.skip("one bf16 trajectory per optimizer family is enough")
+    m = (UMLClip(d, C, logit_scale_init=4.60517, bias=True) if kind == "clip" else UML(d, 0, C, bias=True)).to(DEV)
+    m.load_state_dict({"head.weight": torch.as_tensor(g[f"{tag}::w0"]), "head.bias": torch.as_tensor(g[f"{tag}::b0"])})
+    xi, yi, xt, yt = (_t(g[f"{tag}::{k}"], dt) for k, dt in (("xi", torch.float32), ("yi", torch.int64), ("xt", torch.float32), ("yt", torch.int64)))
+    ii, ti = g[f"{tag}::idx_i"], g[f"{tag}::idx_t"]
+    li, lt = m(xi[_t(ii[0], torch.int64)], xt[_t(ti[0], torch.int64)])
+    np.testing.assert_allclose(li.cpu().numpy(), g[f"{tag}::logits_img0"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(lt.cpu().numpy(), g[f"{tag}::logits_txt0"], atol=1e-4, rtol=1e-5)
+    opt = build_optimizer(m.parameters(), optim, 1e-3, float(wd))
+    sch = build_lr_scheduler(opt, "cosine", 2, 100, warmup_type="linear", warmup_lr=1e-5)
+    eng = m.fused_engine(opt, 64, 64, precision=precision)
+    sc = torch.zeros(steps, umlh.N_SCALARS, device=DEV)
+    for k in range(steps):
+        assert abs(opt.param_groups[0]["lr"] - float(g[f"{tag}::lrs"][k])) < 1e-12
+        eng.train_step(umlh.RowBatch(xi, yi, _t(ii[k], torch.int64)), umlh.RowBatch(xt, yt, _t(ti[k], torch.int64)),
+                       lr=opt.param_groups[0]["lr"], step=k + 1, alpha=float(alpha), scalars_out=sc[k])
+        opt.step_count += 1
+        sch.step()
+    torch.cuda.synchronize()
+    got = sc.cpu().numpy()[:, [umlh.S_LOSS_IMG, umlh.S_LOSS_TXT]]
+    tol = 1e-4 if precision == "fp32" else 0.05
+    np.testing.assert_allclose(got, g[f"{tag}::losses"], atol=tol * max(1.0, np.abs(g[f"{tag}::losses"]).max() if precision == "bf16" else 1.0), rtol=1e-5 if precision == "fp32" else 5e-3)
+    w1, b1 = m.head.weight.detach().cpu().numpy(), m.head.bias.detach().cpu().numpy()
+    lim = 2 * float(np.sum(g[f"{tag}::lrs"])) + 1e-6                       # Adam's first steps move a weight by ~lr * sign(g)
+    for got_p, ref in ((w1, g[f"{tag}::w1"]), (b1, g[f"{tag}::b1"])):
+        diff = np.abs(got_p - ref)
+        if precision == "fp32":
+            assert diff.max() <= lim and (diff > 2e-6 + 1e-4 * np.abs(ref)).mean() < 5e-3
+        else:
+            assert diff.max() <= lim
+    assert float(m._packed[:, d + 1:].abs().max()) == 0.0                  # the padding columns never move
+    # the optimizer's state is visible under the reference's parameter names
+    st = opt.state[m.head.bias]
+    assert any(v.shape == (C,) for v in st.values())

@@ -143,7 +143,7 @@ def test_model_surface_and_seed_parity_of_init():
     assert c.shared_dim == 512 and c.img_proj is None and abs(float(c._scales[0]) - 1 / 0.07) < 1e-3
     assert hasattr(c, "extract_features") and hasattr(m, "extract_raw_features") and hasattr(m, "zero_shot_init")
     with pytest.raises(NotImplementedError):
-        UML(8, 0, 3, bias=True)
+        UML(8, 4, 3, bias=True)                              # bias together with img_proj (see the bias-head test below)
     with pytest.raises(ValueError):
         UML("vit_base_patch16_224", 0, 3)
 
@@ -184,3 +184,25 @@ def test_multibench_dropout_seeds_do_not_consume_the_global_cpu_generator():
     torch.manual_seed(5)
     enc2 = Transformer(8, 10, nhead=5, num_layers=1)
     assert enc2._dropout_seed() == a                     # still fixed by torch.manual_seed
+
+
+def test_bias_head_keeps_reference_parameter_surface():
+    """bias=True (engine/models/head.py:65,68,122): head.weight / head.bias keep the reference's names and shapes while
+    living as views of one packed [C, d_aug] tensor; state_dict round-trips; img_proj + bias is refused loudly."""
+    import pytest
+    import torch
+    from engine.models.head import UML, UMLClip
+    torch.manual_seed(0)
+    m = UMLClip("ViT-B/16", 10, bias=True)
+    assert tuple(m.head.weight.shape) == (10, 512) and tuple(m.head.bias.shape) == (10,)
+    assert set(m.state_dict()) == {"head.weight", "head.bias"}
+    assert m._packed.shape == (10, 640) and float(m._packed[:, 513:].abs().max()) == 0.0
+    assert m.head.weight.data_ptr() == m._packed.data_ptr()                      # views, not copies
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m2 = UMLClip("ViT-B/16", 10, bias=True)
+    m2.load_state_dict(sd)
+    assert torch.equal(m2._packed[:, :512], sd["head.weight"]) and torch.equal(m2._packed[:, 512], sd["head.bias"])
+    u = UML(96, 0, 7, bias=True)
+    assert u._packed.shape == (7, 128) and torch.equal(u._packed[:, 96], u.head.bias.data)
+    with pytest.raises(NotImplementedError):
+        UML(96, 64, 7, bias=True)

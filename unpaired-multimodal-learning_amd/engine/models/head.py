@@ -12,6 +12,9 @@ In this build the backbone is the identity over PRE-EXTRACTED feature rows
     model.head.weight, model.img_proj, model.num_classes, model.shared_dim,
     model.extract_features, model.extract_raw_features, model.zero_shot_init(text_ds)
 
+``bias=True`` is supported for the linear heads (no img_proj): weight and bias are views of one packed tensor and the
+kernels see rows [x | 1 | 0...] (see ``_HeadBase._pack_head``).
+
 ``forward`` returns the logits tensors (computed by ``umlh_logits``); training
 goes through ``fused_engine(optimizer)`` -> ``HeadEngine.train_step`` which never
 materialises logits (see finetune.train in this package).
@@ -93,8 +96,8 @@ def get_zero_shot_weights(text_dataset, num_classes, in_features, device="cuda")
 
 class _HeadBase(nn.Module):
     def _init_common(self, backbone, shared_dim, num_classes, bias, scales, learnable):
-        if bias:
-            raise NotImplementedError("the reference always builds the head with bias=False (finetune.py:338,344)")
+        self._bias = bool(bias)
+        self._packed = None              # bias=True: [C, d_aug] = [weight | bias | 0...], the tensor the kernels own
         self.num_classes = num_classes
         self.vision_model = backbone
         self.shared_dim = shared_dim
@@ -117,7 +120,42 @@ class _HeadBase(nn.Module):
         return self
 
     def _after_move(self):
-        pass
+        self._pack_head()
+
+    # ---- head with bias (head.py:65,68 ``bias=True``) -----------------------------------
+    # The kernels run a bias-free head over rows [x | 1 | 0...] (HeadEngine ``bias_from``): ``head.weight`` and ``head.bias``
+    # are VIEWS of one packed [C, d_aug] tensor (d_aug = d + 1 rounded up to 128: valid for both precision modes), so the
+    # reference's parameter names, shapes, initialisation and state_dict keys stay as they are.
+    def _pack_head(self):
+        if not getattr(self, "_bias", False) or not hasattr(self, "head"):
+            return
+        w, b = self.head.weight, self.head.bias
+        C, d = w.shape
+        d_aug = (d + 1 + 127) // 128 * 128
+        packed = torch.zeros(C, d_aug, dtype=torch.float32, device=w.device)
+        packed[:, :d] = w.data
+        packed[:, d] = b.data
+        self._packed = packed
+        w.data = packed[:, :d]
+        b.data = packed[:, d]
+
+    def _packed_state(self, optimizer, opt_name):
+        """Optimizer moments of (weight, bias) as views of packed [C, d_aug] tensors (what the kernels update)."""
+        pk = getattr(optimizer, "_packed_head_state", None)
+        w, b = self.head.weight, self.head.bias
+        d = w.shape[1]
+        if pk is None or pk[0].shape != self._packed.shape or pk[0].device != self._packed.device:
+            names = ["momentum_buffer"] if opt_name == "sgd" else ["exp_avg", "exp_avg_sq"]
+            pk = tuple(torch.zeros_like(self._packed) for _ in names)
+            for t, nm in zip(pk, names):                     # adopt moments the optimizer may already hold (resumed state)
+                for p, view in ((w, t[:, :d]), (b, t[:, d])):
+                    old = optimizer.state.get(p, {}).get(nm)
+                    if old is not None:
+                        view.copy_(old)
+            optimizer.state[w] = {nm: t[:, :d] for t, nm in zip(pk, names)}
+            optimizer.state[b] = {nm: t[:, d] for t, nm in zip(pk, names)}
+            optimizer._packed_head_state = pk
+        return pk
 
     # ---- fused path ------------------------------------------------------------------
     @property
@@ -141,6 +179,23 @@ class _HeadBase(nn.Module):
             return eng
         g = optimizer.param_groups[0] if optimizer is not None else dict(weight_decay=0.0, betas=(0.9, 0.999),
                                                                          eps=1e-8, momentum=0.9)
+        if self._bias:
+            d_aug = self._packed.shape[1]
+            eng = umlh.HeadEngine(d_aug, d_aug, self.num_classes, has_proj=False, learnable_temp=self._learnable_temp,
+                                  optimizer=opt_name, weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"],
+                                  momentum=g["momentum"], max_rows_img=max_rows_img, max_rows_txt=max_rows_txt,
+                                  precision=precision, device=dev, bias_from=self.shared_dim)
+            bind = dict(w_head=self._packed, scales=self._scales)
+            if optimizer is not None:
+                pk = self._packed_state(optimizer, opt_name)
+                bind["m_head"] = pk[0]
+                if len(pk) > 1:
+                    bind["v_head"] = pk[1]
+            eng.rebind(**bind)
+            if optimizer is not None and self._learnable_temp:
+                raise NotImplementedError("bias=True with learnable_temp: not wired (the reference never builds it)")
+            self._engines[key] = eng
+            return eng
         eng = umlh.HeadEngine(self.vision_model.num_features, self.shared_dim, self.num_classes,
                               has_proj=self._has_proj, learnable_temp=self._learnable_temp, optimizer=opt_name,
                               weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"], momentum=g["momentum"],
@@ -230,9 +285,13 @@ class UML(_HeadBase):
         # parameter creation order == reference (img_proj, head, img_scale, txt_scale): the
         # nn.Linear initialisers consume the global RNG identically (seed parity)
         if text_indim > 0:
+            if bias:
+                # the head's bias needs a constant-1 column in the PROJECTED rows: a frozen row of img_proj the optimizer
+                # kernels would have to skip -- not built (the reference never constructs bias=True: finetune.py:338,344,346)
+                raise NotImplementedError("bias=True together with img_proj (text_indim > 0) is not supported")
             self.img_proj = nn.Linear(backbone.num_features, text_indim, bias=False)
             self.shared_dim = text_indim
-        self.head = nn.Linear(self.shared_dim, num_classes, bias=False)
+        self.head = nn.Linear(self.shared_dim, num_classes, bias=bool(bias))
         if learnable_temp:
             self.img_scale = nn.Parameter(torch.tensor(1.0))
             self.txt_scale = nn.Parameter(torch.tensor(1.0))
@@ -245,6 +304,7 @@ class UML(_HeadBase):
         # keep img_scale / txt_scale as views of the packed device float[2]
         if not hasattr(self, "head"):
             return
+        self._pack_head()
         dev = self.head.weight.device
         vals = torch.stack([self.img_scale.detach().to(dev, torch.float32).reshape(()),
                             self.txt_scale.detach().to(dev, torch.float32).reshape(())])
@@ -273,8 +333,9 @@ class UMLClip(_HeadBase):
         self.img_proj = None
         s = math.exp(float(logit_scale_init))
         self._init_common(backbone, backbone.embed_dim, num_classes, bias, [s, s], False)
-        self.head = nn.Linear(self.shared_dim, num_classes, bias=False)
+        self.head = nn.Linear(self.shared_dim, num_classes, bias=bool(bias))
         self.logit_scale = torch.tensor(float(logit_scale_init))      # fixed scale (head.py:125)
+        self._pack_head()
 
     def extract_features(self, images):
         """Missing in the reference class although train() calls it; identity here."""

@@ -48,7 +48,11 @@ class HeadEngine:
                  learnable_temp: bool = False, optimizer: str = "adamw", weight_decay: float = 0.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9,
                  max_rows_img: int = 4096, max_rows_txt: int = 4096, precision: str = "fp32",
-                 device="cuda:0"):
+                 device="cuda:0", bias_from: Optional[int] = None):
+        """``bias_from = d``: a linear head WITH bias (engine/models/head.py:65,68 ``bias=True``) over d-wide features, run
+        as a bias-free head over ``d_shared``-wide rows [x | 1 | 0...]: column d of every feature row is 1 (appended here, cached
+        per table), column d of ``w_head`` is the bias, columns beyond are zero padding that stays zero (zero gradient; AdamW's
+        decay of 0 is 0).  Same logits ``x W^T + b``, same gradients and optimizer recurrences for weight and bias."""
         if optimizer not in OPT_IDS:   # engine/optimizer/optim.py:22
             raise AssertionError(f"Optimizer {optimizer} not found; available optimizers = {list(OPT_IDS)}")
         self.lib = _lib.load_library()
@@ -70,6 +74,10 @@ class HeadEngine:
         self.has_proj, self.learnable_temp, self.optimizer = bool(has_proj), bool(learnable_temp), optimizer
         self.precision = precision
         self.d_img, self.d_shared, self.num_classes = d_img, d_shared, num_classes
+        self.bias_from = None if bias_from is None else int(bias_from)
+        if self.bias_from is not None and (has_proj or d_img != d_shared or not 0 < self.bias_from < d_shared):
+            raise UmlhError("bias_from: linear heads only (no img_proj), with d_img == d_shared > bias_from")
+        self._aug_cache = {}                 # (data_ptr, rows, version) -> (fp32 augmented rows, bf16 shadow or None)
         self.w_head = torch.zeros(num_classes, d_shared, **f32)
         self.m_head = torch.zeros_like(self.w_head)
         self.v_head = torch.zeros_like(self.w_head)
@@ -116,6 +124,26 @@ class HeadEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _augment(self, f: torch.Tensor, want16: bool):
+        """[N, d] feature rows -> ([N, d_shared] rows [x | 1 | 0...], bf16 shadow or None) for a head with bias.  Tables are
+        converted once (cached by address, row count and in-place version); rows that already have the engine's width
+        pass through."""
+        if self.bias_from is None or f.dim() != 2 or f.shape[1] != self.bias_from:
+            return f, None
+        key = (f.data_ptr(), int(f.shape[0]), int(f._version))
+        hit = self._aug_cache.pop(key, None)
+        if hit is None:
+            a = torch.zeros(f.shape[0], self.d_shared, dtype=torch.float32, device=f.device)
+            a[:, :self.bias_from] = f
+            a[:, self.bias_from] = 1.0
+            hit = (a, None)
+        if want16 and hit[1] is None:
+            hit = (hit[0], to_bf16(hit[0]))
+        self._aug_cache[key] = hit           # most recently used last
+        while len(self._aug_cache) > 32:
+            self._aug_cache.pop(next(iter(self._aug_cache)))
+        return hit
+
     def _batch(self, b: Optional[RowBatch], dim: int) -> Optional[Batch]:
         if b is None:
             return None
@@ -124,6 +152,11 @@ class HeadEngine:
             # data-parallel split: an empty local shard still tells the update that the modality has rows elsewhere
             return Batch(None, None, None, 0, int(b.global_rows), None) if b.global_rows else None
         f, y = b.feats, b.labels
+        f16_aug = None
+        if self.bias_from is not None and f.dim() == 2 and f.shape[1] == self.bias_from:
+            if f.dtype != torch.float32 or not f.is_contiguous():
+                raise UmlhError(f"features must be contiguous fp32, got {f.dtype} {tuple(f.shape)}")
+            f, f16_aug = self._augment(f, self.precision == "bf16")
         if f.dtype != torch.float32 or not f.is_contiguous() or f.dim() != 2 or f.shape[1] != dim:
             raise UmlhError(f"features must be contiguous fp32 [N,{dim}], got {f.dtype} {tuple(f.shape)}")
         if y.dtype != torch.int64 or not y.is_contiguous():
@@ -137,7 +170,7 @@ class HeadEngine:
                 raise UmlhError("index shorter than rows")
         elif f.shape[0] < rows:
             raise UmlhError("feature table shorter than rows")
-        f16 = b.feats_bf16
+        f16 = b.feats_bf16 if f16_aug is None else f16_aug
         if self.precision == "bf16":
             if f16 is None:                       # dense batch without a cached shadow: convert now (HIP kernel)
                 f16 = b.feats_bf16 = to_bf16(f)
@@ -152,6 +185,8 @@ class HeadEngine:
     # -- C ABI calls -----------------------------------------------------------------
     def zero_shot_init(self, text_feats: torch.Tensor, text_labels: torch.Tensor) -> None:
         """head.weight.data = get_zero_shot_weights(...)  (engine/models/head.py:22-37,96-98)."""
+        if self.bias_from is not None:
+            raise UmlhError("zero_shot_init: initialise the d-wide weight with a bias-free engine (get_zero_shot_weights)")
         tf = text_feats.to(self.device, torch.float32).contiguous()
         tl = text_labels.to(self.device, torch.int64).contiguous()
         if tf.shape[1] != self.d_shared:
@@ -195,6 +230,8 @@ class HeadEngine:
             return None, None
         f, y = table[0], table[1]
         f16 = table[2] if len(table) > 2 else None
+        if self.bias_from is not None and f.dim() == 2 and f.shape[1] == self.bias_from and f.dtype == torch.float32 and f.is_contiguous():
+            f, f16 = self._augment(f, self.precision == "bf16")
         if f.dtype != torch.float32 or not f.is_contiguous() or f.shape[1] != dim or y.dtype != torch.int64:
             raise UmlhError("train_steps: table must be contiguous fp32 [N,dim] + int64 labels")
         if self.precision == "bf16" and (f16 is None or f16.dtype != torch.bfloat16 or f16.shape != f.shape):
