@@ -127,7 +127,7 @@ typedef struct {
 #define UMLH_N_SCALARS    12
 
 const char* umlh_last_error(void);
-int  umlh_version(void);
+int  umlh_version(void);        /* ABI revision: 3 = round 2 (grouped / micro / data-parallel / encoder-plan / InfoNCE entry points) */
 
 /* Bytes of workspace a handle with this config needs (0 on invalid config). */
 uint64_t umlh_workspace_bytes(const umlh_config_t* cfg);

@@ -239,7 +239,7 @@ static inline void mark(umlh_handle_t h, int i, hipStream_t st) {
 }
 
 const char* umlh_last_error(void) { return g_err; }
-int umlh_version(void) { return 2; }
+int umlh_version(void) { return 3; }   // 3: round 2 (grouped / micro / data-parallel / encoder-plan / InfoNCE entry points, umlh_enc_layer_t.seed_device, umlh_seq_mse_backward scratch)
 
 int umlh_enable_diagnostics(umlh_handle_t h, int32_t on) {
     if (!h) return fail(UMLH_E_INVALID, "umlh_enable_diagnostics: null handle");
