@@ -70,6 +70,16 @@ class _RowSource:
         t = self.loader.table
         return (t.features, t.labels, t.features_bf16()) if precision == "bf16" else (t.features, t.labels)
 
+    def save(self):
+        """Position of the batch stream (iterator, epoch order, offset): ``restore`` rewinds to it."""
+        it = self.it
+        return it, getattr(it, "order", None), getattr(it, "pos", None)
+
+    def restore(self, st):
+        self.it = st[0]
+        if st[2] is not None:
+            self.it.order, self.it.pos = st[1], st[2]
+
     def next(self) -> umlh.RowBatch:
         batch, self.it = fetch_next(_Reiter(self._make_iter), self.it)
         if self.indexed:
@@ -187,11 +197,74 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
     img_alpha = 1.0
     last_i = -1
     blockwise = logger is None and (img_src is None or img_src.indexed) and (txt_src is None or txt_src.indexed)
+
+    # Evaluation points (finetune.py:247-271).  Blockwise runs read an evaluation's results one block LATE: the evaluation and
+    # its device-to-host copy are enqueued, then the next training block, and only then does the host wait for the copy --
+    # the GPU goes from the evaluation straight into the next block instead of idling while the host reads, decides and
+    # prepares.  If the late result says "early stop", everything the extra block advanced is rewound to the evaluation
+    # point (loader positions and RNG streams, optimizer / scheduler counters and moments; the weights are replaced by the
+    # best snapshot anyway), so train() leaves every object exactly as the reference's loop would.
+    def eval_begin(i):
+        snap = _state_dict_snapshot(model)                    # device-side clone; moved to the CPU on return
+        model.eval()
+        h = validate_many_begin([(model, val_loader)] + ([(model, test_loader)] if test_loader is not None else []),
+                                extra=[scalars[i]])
+        model.train()
+        return {"i": i, "snap": snap, "h": h}
+
+    def eval_end(p):
+        """Bookkeeping of the evaluation at iteration p["i"]; True = stop training."""
+        nonlocal no_improve
+        i = p["i"]
+        res, (s,) = validate_many_end(p["h"])
+        val_loss, val_acc = res[0]
+        testlog = f" | Test Acc: {res[1][1]:.4f}" if test_loader is not None else ""
+        if out["val_acc"] is None or val_acc > out["val_acc"]:
+            out.update(iter=i, val_acc=val_acc, val_loss=val_loss, model=p["snap"])
+            no_improve = 0
+        else:
+            no_improve += 1
+        if logger is not None:
+            logger.log({"val/val_loss": val_loss, "val/val_acc": val_acc, "iter": i})
+        if not bool(torch.isfinite(s).all()):
+            _check_micro(engine)
+        print(f"Iter {i} | Img Loss: {s[umlh.S_LOSS_IMG]:.4f} | Text Loss: {s[umlh.S_LOSS_TXT]:.4f} | "
+              f"Img Acc: {s[umlh.S_ACC_IMG]:.4f} | Text Acc: {s[umlh.S_ACC_TXT]:.4f} | Val Loss: {val_loss:.4f} | "
+              f"Val Acc {val_acc:.4f}{testlog} | Count {no_improve}/{patience}")
+        if no_improve >= patience:
+            print(f"=> Early stopping at Iter {i}")
+            return True
+        return False
+
+    def rewind_point():
+        """Everything a training block advances besides the weights, captured before the block is drawn."""
+        gens = []
+        for src in (img_src, txt_src):
+            g = getattr(src.loader, "generator", None) if src is not None else None
+            if src is not None and all(g is not q for q, _ in gens):
+                gens.append((g, g.get_state() if g is not None else torch.get_rng_state()))
+        moments = [(t, t.clone()) for st in optimizer.state.values() for t in st.values() if torch.is_tensor(t)]
+        return {"src": [(src, src.save()) for src in (img_src, txt_src) if src is not None], "gens": gens, "moments": moments,
+                "step_count": optimizer.step_count, "epoch": scheduler.last_epoch}
+
+    def rewind(r):
+        for src, st in r["src"]:
+            src.restore(st)
+        for g, st in r["gens"]:
+            g.set_state(st) if g is not None else torch.set_rng_state(st)
+        for t, old in r["moments"]:
+            t.copy_(old)
+        optimizer.step_count = r["step_count"]
+        scheduler.step(r["epoch"])
+
+    pending = None            # evaluation whose results have not been read yet (blockwise runs only)
+    stopped = False
     i = 0
     while i < max_iters:
         if blockwise:
             # all steps up to and including the next evaluation point in ONE C call:
             # no Python, no host sync between steps
+            back = rewind_point() if pending is not None else None
             i_end = _block_end(i, max_iters, eval_freq)
             n = i_end - i + 1
             bi, bt = _draw_block(img_src, txt_src, n)
@@ -202,6 +275,13 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
                                scalars_out=scalars[i:i + n])
             optimizer.step_count += n
             scheduler.step(scheduler.last_epoch + n)
+            if pending is not None:
+                p, pending = pending, None
+                if eval_end(p):                               # the block just enqueued ran past an early stop: take it back
+                    rewind(back)
+                    last_i = p["i"]
+                    stopped = True
+                    break
             i = i_end
         else:
             img_rows = img_src.next() if img_src is not None else None
@@ -225,31 +305,15 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
                         "train/txt_grad_norm": gd["txt_grad_norm"], "train/grad_agreement_rate": gd["grad_agreement_rate"],
                         "train/feature_direction_sim": feat_sim})
         if i % eval_freq == 0:
-            state_dict_cpu = _state_dict_snapshot(model)          # device-side clone; moved to the CPU on return
-            model.eval()
-            res, (s,) = validate_many([(model, val_loader)] + ([(model, test_loader)] if test_loader is not None else []),
-                                      extra=[scalars[i]])
-            model.train()
-            val_loss, val_acc = res[0]
-            testlog = ""
-            if test_loader is not None:
-                testlog = f" | Test Acc: {res[1][1]:.4f}"
-            if out["val_acc"] is None or val_acc > out["val_acc"]:
-                out.update(iter=i, val_acc=val_acc, val_loss=val_loss, model=state_dict_cpu)
-                no_improve = 0
-            else:
-                no_improve += 1
-            if logger is not None:
-                logger.log({"val/val_loss": val_loss, "val/val_acc": val_acc, "iter": i})
-            if not bool(torch.isfinite(s).all()):
-                _check_micro(engine)
-            print(f"Iter {i} | Img Loss: {s[umlh.S_LOSS_IMG]:.4f} | Text Loss: {s[umlh.S_LOSS_TXT]:.4f} | "
-                  f"Img Acc: {s[umlh.S_ACC_IMG]:.4f} | Text Acc: {s[umlh.S_ACC_TXT]:.4f} | Val Loss: {val_loss:.4f} | "
-                  f"Val Acc {val_acc:.4f}{testlog} | Count {no_improve}/{patience}")
-            if no_improve >= patience:
-                print(f"=> Early stopping at Iter {i}")
+            p = eval_begin(i)
+            if blockwise and i + 1 < max_iters:
+                pending = p                                   # read after the next block has been enqueued
+            elif eval_end(p):
+                stopped = True
                 break
         i += 1
+    if pending is not None and not stopped:
+        eval_end(pending)
     _check_micro(engine)
     model.load_state_dict(out["model"])
     out["model"] = _to_cpu(out["model"])
@@ -379,6 +443,53 @@ def _eval_finish(stats_cpu, bs):
     counts = np.full(nb, bs, dtype=np.float64)
     counts[-1] = n - (nb - 1) * bs
     return float((sums / counts).sum() / nb), float(st[:, 1].sum() / n)
+
+
+_PINNED = []        # ring of pinned host buffers for the evaluation read-backs (hipHostMalloc per call would cost more than the copy)
+
+
+def _pinned(n):
+    for k, buf in enumerate(_PINNED):
+        if buf.numel() >= n:
+            _PINNED.append(_PINNED.pop(k))                 # least recently handed out first
+            return _PINNED[-1][:n]
+    if len(_PINNED) >= 4:
+        _PINNED.pop(0)
+    _PINNED.append(torch.empty(max(n, 1 << 16), dtype=torch.float32, pin_memory=True))
+    return _PINNED[-1][:n]
+
+
+def validate_many_begin(pairs, extra=None):
+    """First half of ``validate_many``: enqueue every evaluation and ONE asynchronous device-to-host copy of all per-row
+    statistics (+ ``extra``) into pinned memory; returns a handle for ``validate_many_end``.  Nothing waits for the GPU:
+    the caller can enqueue the next training block before it looks at the results."""
+    extra = list(extra or [])
+    if not all(_slab_evaluable(ld) for _, ld in pairs):
+        return {"done": ([validate(m, ld) for m, ld in pairs], [e.cpu() for e in extra])}
+    stats = [_eval_enqueue(m, ld) for m, ld in pairs]
+    dev_flat = torch.cat([st.reshape(-1) for st in stats] + [e.reshape(-1).to(torch.float32) for e in extra])
+    host = _pinned(dev_flat.numel())
+    host.copy_(dev_flat, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev_flat.device))
+    return {"host": host, "event": ev, "keep": dev_flat, "pairs": pairs, "sizes": [st.numel() for st in stats], "extra": extra}
+
+
+def validate_many_end(h):
+    """(results, extras on the CPU) of a ``validate_many_begin`` handle; waits for its copy only."""
+    if "done" in h:
+        return h["done"]
+    h["event"].synchronize()
+    flat = h["host"].clone()                               # the pinned buffer goes back to the ring
+    out, pos = [], 0
+    for (m, ld), n in zip(h["pairs"], h["sizes"]):
+        out.append(_eval_finish(flat[pos:pos + n].reshape(-1, 2), ld.batch_size))
+        pos += n
+    ex = []
+    for e in h["extra"]:
+        ex.append(flat[pos:pos + e.numel()].reshape(e.shape))
+        pos += e.numel()
+    return out, ex
 
 
 def validate_many(pairs, extra=None):
