@@ -142,6 +142,11 @@ int  umlh_bind(umlh_handle_t h, const umlh_buffers_t* bufs);
  * every step with two extra backward passes; here they ride on the slab reduction).  Off by default. */
 int  umlh_enable_diagnostics(umlh_handle_t h, int32_t on);
 
+/* img_proj WITH bias (head.py:65 `bias=True`, run as a bias-free projection over rows [x | 1 | 0...]): row `row` of w_proj is the
+ * constant row that copies the ones column into the projected rows (the head's own bias column needs it); the optimizer
+ * leaves that row, and its moments, untouched.  row < 0 clears.  Needs d_img % 4 == 0. */
+int  umlh_freeze_proj_row(umlh_handle_t h, int32_t row);
+
 /* head.weight.data = get_zero_shot_weights(...)  head.py:22-37,96-98: per-class
  * mean of the text rows (rows of classes without text stay 0), rows L2-normalised. */
 int  umlh_zero_shot_init(umlh_handle_t h, const float* text_feats, const int64_t* text_labels,

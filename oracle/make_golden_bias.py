@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import make_golden as G   # noqa: E402  (stubs the absent third-party packages, imports the reference)
 
 
-def case(rec, tag, kind, d, C, Bi, Bt, optim, wd, steps, alpha, seed):
+def case(rec, tag, kind, d, C, Bi, Bt, optim, wd, steps, alpha, seed, text_indim=0):
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed + 1)
     if kind == "clip":
@@ -20,14 +20,18 @@ def case(rec, tag, kind, d, C, Bi, Bt, optim, wd, steps, alpha, seed):
         m.head = torch.nn.Linear(d, C, bias=True)                       # head.py:122 with bias=True
     else:
         G._FEAT_D["d"] = d
-        m = G.quiet(G.RefUML, "identity", 0, C, bias=True, learnable_temp=False, freeze_backbone=False)
+        m = G.quiet(G.RefUML, "identity", text_indim, C, bias=True, learnable_temp=False, freeze_backbone=False)   # head.py:65,68
     with torch.no_grad():
         m.head.weight.mul_(3.0)
         m.head.bias.uniform_(-0.5, 0.5, generator=gen)
+        if text_indim:
+            m.img_proj.bias.uniform_(-0.3, 0.3, generator=gen)
     n = 200
     xi, yi = G.synth(n, d, C, gen)
-    xt, yt = G.synth(n, d, C, gen)
+    xt, yt = G.synth(n, text_indim or d, C, gen)
     rec[f"{tag}::w0"], rec[f"{tag}::b0"] = m.head.weight.detach().clone(), m.head.bias.detach().clone()
+    if text_indim:
+        rec[f"{tag}::pw0"], rec[f"{tag}::pb0"] = m.img_proj.weight.detach().clone(), m.img_proj.bias.detach().clone()
     rec[f"{tag}::xi"], rec[f"{tag}::yi"], rec[f"{tag}::xt"], rec[f"{tag}::yt"] = xi, yi, xt, yt
     opt = G.ref_build_optimizer(m.parameters(), optim, 1e-3, wd)
     sch = G.ref_build_sched(opt, "cosine", 2, 100, warmup_type="linear", warmup_lr=1e-5)
@@ -52,7 +56,9 @@ def case(rec, tag, kind, d, C, Bi, Bt, optim, wd, steps, alpha, seed):
     rec[f"{tag}::idx_i"], rec[f"{tag}::idx_t"] = torch.stack(idx_i), torch.stack(idx_t)
     rec[f"{tag}::losses"], rec[f"{tag}::lrs"] = np.asarray(losses), np.asarray(lrs)
     rec[f"{tag}::w1"], rec[f"{tag}::b1"] = m.head.weight.detach().clone(), m.head.bias.detach().clone()
-    rec[f"{tag}::cfg"] = np.asarray([d, C, Bi, Bt, steps, alpha, wd, {"adamw": 2, "adam": 1, "sgd": 0}[optim]], dtype=np.float64)
+    if text_indim:
+        rec[f"{tag}::pw1"], rec[f"{tag}::pb1"] = m.img_proj.weight.detach().clone(), m.img_proj.bias.detach().clone()
+    rec[f"{tag}::cfg"] = np.asarray([d, C, Bi, Bt, steps, alpha, wd, {"adamw": 2, "adam": 1, "sgd": 0}[optim], text_indim], dtype=np.float64)
     print(tag, losses[0], losses[-1])
 
 
@@ -62,4 +68,5 @@ if __name__ == "__main__":
     case(rec, "clip_d64_c10_adamw", "clip", 64, 10, 32, 32, "adamw", 0.01, 8, 1.0, seed=1)
     case(rec, "uml_d96_c37_sgd", "uml", 96, 37, 20, 33, "sgd", 1e-3, 8, 0.5, seed=2)
     case(rec, "clip_d512_c100_adam", "clip", 512, 100, 32, 32, "adam", 0.0, 6, 1.0, seed=3)
+    case(rec, "mlp_d48_t64_c10_adamw", "uml", 48, 10, 24, 40, "adamw", 0.01, 8, 0.7, seed=4, text_indim=64)   # img_proj + both biases
     G.npz("bias_heads", **rec)

@@ -325,7 +325,8 @@ def test_gradient_diagnostics_are_bitwise_reproducible():
         assert np.array_equal(r, rows[0])
 
 
-@pytest.mark.parametrize("tag,kind", [("clip_d64_c10_adamw", "clip"), ("uml_d96_c37_sgd", "uml"), ("clip_d512_c100_adam", "clip")])
+@pytest.mark.parametrize("tag,kind", [("clip_d64_c10_adamw", "clip"), ("uml_d96_c37_sgd", "uml"), ("clip_d512_c100_adam", "clip"),
+                                      ("mlp_d48_t64_c10_adamw", "uml")])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_head_with_bias_matches_reference(tag, kind, precision):
     """bias=True heads (engine/models/head.py:65,68,122) against the reference's own classes, autograd and optimizers
@@ -337,13 +338,16 @@ def test_head_with_bias_matches_reference(tag, kind, precision):
     from engine.optimizer.optim import build_optimizer
     from engine.optimizer.scheduler import build_lr_scheduler
     g = load_golden("bias_heads")
-    d, C, Bi, Bt, steps, alpha, wd, oid = g[f"{tag}::cfg"]
-    d, C, steps = int(d), int(C), int(steps)
+    d, C, Bi, Bt, steps, alpha, wd, oid, t_in = g[f"{tag}::cfg"]
+    d, C, steps, t_in = int(d), int(C), int(steps), int(t_in)
     optim = {2: "adamw", 1: "adam", 0: "sgd"}[int(oid)]
     if precision == "bf16" and optim == "sgd":
         pytest.skip("one bf16 trajectory per optimizer family is enough")
-    m = (UMLClip(d, C, logit_scale_init=4.60517, bias=True) if kind == "clip" else UML(d, 0, C, bias=True)).to(DEV)
-    m.load_state_dict({"head.weight": torch.as_tensor(g[f"{tag}::w0"]), "head.bias": torch.as_tensor(g[f"{tag}::b0"])})
+    m = (UMLClip(d, C, logit_scale_init=4.60517, bias=True) if kind == "clip" else UML(d, t_in, C, bias=True)).to(DEV)
+    sd = {"head.weight": torch.as_tensor(g[f"{tag}::w0"]), "head.bias": torch.as_tensor(g[f"{tag}::b0"])}
+    if t_in:                                                               # 2-layer head: img_proj carries a bias too
+        sd.update({"img_proj.weight": torch.as_tensor(g[f"{tag}::pw0"]), "img_proj.bias": torch.as_tensor(g[f"{tag}::pb0"])})
+    m.load_state_dict(sd)
     xi, yi, xt, yt = (_t(g[f"{tag}::{k}"], dt) for k, dt in (("xi", torch.float32), ("yi", torch.int64), ("xt", torch.float32), ("yt", torch.int64)))
     ii, ti = g[f"{tag}::idx_i"], g[f"{tag}::idx_t"]
     li, lt = m(xi[_t(ii[0], torch.int64)], xt[_t(ti[0], torch.int64)])
@@ -365,13 +369,23 @@ def test_head_with_bias_matches_reference(tag, kind, precision):
     np.testing.assert_allclose(got, g[f"{tag}::losses"], atol=tol * max(1.0, np.abs(g[f"{tag}::losses"]).max() if precision == "bf16" else 1.0), rtol=1e-5 if precision == "fp32" else 5e-3)
     w1, b1 = m.head.weight.detach().cpu().numpy(), m.head.bias.detach().cpu().numpy()
     lim = 2 * float(np.sum(g[f"{tag}::lrs"])) + 1e-6                       # Adam's first steps move a weight by ~lr * sign(g)
-    for got_p, ref in ((w1, g[f"{tag}::w1"]), (b1, g[f"{tag}::b1"])):
+    pairs = [(w1, g[f"{tag}::w1"]), (b1, g[f"{tag}::b1"])]
+    if t_in:
+        pairs += [(m.img_proj.weight.detach().cpu().numpy(), g[f"{tag}::pw1"]), (m.img_proj.bias.detach().cpu().numpy(), g[f"{tag}::pb1"])]
+        row = m._packed_proj[t_in].cpu().numpy()                           # the constant row never moves
+        assert row[d] == 1.0 and np.abs(row).sum() == 1.0
+        feats = m.extract_features(xi[:5])
+        ref_h = xi[:5].cpu().numpy() @ g[f"{tag}::pw1"].T + g[f"{tag}::pb1"]
+        assert tuple(feats.shape) == (5, t_in)
+        if precision == "fp32":
+            np.testing.assert_allclose(feats.cpu().numpy(), ref_h, atol=5e-3)
+    for got_p, ref in pairs:
         diff = np.abs(got_p - ref)
         if precision == "fp32":
             assert diff.max() <= lim and (diff > 2e-6 + 1e-4 * np.abs(ref)).mean() < 5e-3
         else:
             assert diff.max() <= lim
-    assert float(m._packed[:, d + 1:].abs().max()) == 0.0                  # the padding columns never move
+    assert float(m._packed[:, (t_in or d) + 1:].abs().max()) == 0.0        # the padding columns never move
     # the optimizer's state is visible under the reference's parameter names
     st = opt.state[m.head.bias]
     assert any(v.shape == (C,) for v in st.values())

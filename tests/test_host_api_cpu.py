@@ -142,8 +142,6 @@ def test_model_surface_and_seed_parity_of_init():
     c = UMLClip("ViT-B/16", 10)
     assert c.shared_dim == 512 and c.img_proj is None and abs(float(c._scales[0]) - 1 / 0.07) < 1e-3
     assert hasattr(c, "extract_features") and hasattr(m, "extract_raw_features") and hasattr(m, "zero_shot_init")
-    with pytest.raises(NotImplementedError):
-        UML(8, 4, 3, bias=True)                              # bias together with img_proj (see the bias-head test below)
     with pytest.raises(ValueError):
         UML("vit_base_patch16_224", 0, 3)
 
@@ -188,7 +186,7 @@ def test_multibench_dropout_seeds_do_not_consume_the_global_cpu_generator():
 
 def test_bias_head_keeps_reference_parameter_surface():
     """bias=True (engine/models/head.py:65,68,122): head.weight / head.bias keep the reference's names and shapes while
-    living as views of one packed [C, d_aug] tensor; state_dict round-trips; img_proj + bias is refused loudly."""
+    living as views of one packed [C, d_aug] tensor; state_dict round-trips; with img_proj both layers are packed."""
     import pytest
     import torch
     from engine.models.head import UML, UMLClip
@@ -204,5 +202,10 @@ def test_bias_head_keeps_reference_parameter_surface():
     assert torch.equal(m2._packed[:, :512], sd["head.weight"]) and torch.equal(m2._packed[:, 512], sd["head.bias"])
     u = UML(96, 0, 7, bias=True)
     assert u._packed.shape == (7, 128) and torch.equal(u._packed[:, 96], u.head.bias.data)
-    with pytest.raises(NotImplementedError):
-        UML(96, 64, 7, bias=True)
+    # 2-layer head: both layers packed; row d_sh of the packed projection is the constant row (1 at the ones column)
+    p2 = UML(96, 64, 7, bias=True)
+    assert set(p2.state_dict()) == {"img_proj.weight", "img_proj.bias", "head.weight", "head.bias"}
+    assert p2._packed.shape == (7, 128) and p2._packed_proj.shape == (128, 128)
+    assert tuple(p2.img_proj.weight.shape) == (64, 96) and tuple(p2.img_proj.bias.shape) == (64,)
+    assert float(p2._packed_proj[64, 96]) == 1.0 and float(p2._packed_proj[64].sum()) == 1.0
+    assert torch.equal(p2._packed_proj[:64, 96], p2.img_proj.bias.data) and float(p2._packed_proj[65:].abs().max()) == 0.0

@@ -23,7 +23,8 @@ int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t
 int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream);
 int umlh_f32_launch_gemm_enc(const GemmArgs* g, int ta, int tb, int splits, hipStream_t stream);
 int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long long slab_stride, long long n,
-                              float* grad_out, float* p, float* m, float* v, const OptArgs* o, hipStream_t stream);
+                              float* grad_out, float* p, float* m, float* v, const OptArgs* o, long long frozen_lo,
+                              long long frozen_hi, hipStream_t stream);
 int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream);
 int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
                           float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out,
@@ -202,6 +203,7 @@ struct umlh_handle_s {
     int micro_off;              // UMLH_MICRO=0: never take the micro path
     long long micro_launches;   // persistent launches this handle took part in (tests assert the path that ran)
     // data-parallel stepping
+    int frozen_proj_row;        // umlh_freeze_proj_row: row of w_proj the optimizer leaves alone (-1 = none)
     bool dp_diag;               // layout of the gradient message: [g_img | g_txt | g_proj | g_scales | scalars] instead of [g_head | ...]
     int n_ranks;                // > 1 (or dp_force): umlh_train_steps runs grad -> all-reduce -> update per step
     int dp_force;               // UMLH_FORCE_DP=1 / umlh_set_allreduce with one rank: take the split path also alone (pricing, tests)
@@ -240,6 +242,14 @@ static inline void mark(umlh_handle_t h, int i, hipStream_t st) {
 
 const char* umlh_last_error(void) { return g_err; }
 int umlh_version(void) { return 3; }   // 3: round 2 (grouped / micro / data-parallel / encoder-plan / InfoNCE entry points, umlh_enc_layer_t.seed_device, umlh_seq_mse_backward scratch)
+
+int umlh_freeze_proj_row(umlh_handle_t h, int32_t row) {
+    if (!h) return fail(UMLH_E_INVALID, "umlh_freeze_proj_row: null handle");
+    if (row >= 0 && (!h->cfg.has_proj || row >= h->cfg.d_shared || h->cfg.d_img % 4 != 0))
+        return fail(UMLH_E_INVALID, "umlh_freeze_proj_row: row %d of a [%d, %d] img_proj (needs img_proj and d_img %% 4 == 0)", row, h->cfg.d_shared, h->cfg.d_img);
+    h->frozen_proj_row = row < 0 ? -1 : row;
+    return UMLH_OK;
+}
 
 int umlh_enable_diagnostics(umlh_handle_t h, int32_t on) {
     if (!h) return fail(UMLH_E_INVALID, "umlh_enable_diagnostics: null handle");
@@ -286,6 +296,7 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->profiling = false;
     h->micro_epoch = 0;
     h->micro_launches = 0;
+    h->frozen_proj_row = -1;
     h->dp_diag = false; h->n_ranks = 1; h->ar_fn = nullptr; h->ar_ctx = nullptr; h->comm = nullptr; h->comm_owned = false;
     h->comm_stream = nullptr; h->overlap_pending = false;
     { const char* e = getenv("UMLH_FORCE_DP"); h->dp_force = (e && atoi(e) == 1) ? 1 : 0; }
@@ -347,6 +358,8 @@ int umlh_destroy(umlh_handle_t h) {
 static inline float* ws(umlh_handle_t h, long long off) { return static_cast<float*>(h->buf.workspace) + off; }
 
 // gradient message layout (see umlh_grad_step): head part, img_proj part, then g_scales(2) + scalars
+static inline long long frozen_lo(const umlh_handle_s* h) { return h->frozen_proj_row < 0 ? 0 : (long long)h->frozen_proj_row * h->cfg.d_img; }
+static inline long long frozen_hi(const umlh_handle_s* h) { return h->frozen_proj_row < 0 ? 0 : (long long)(h->frozen_proj_row + 1) * h->cfg.d_img; }
 static inline long long msg_head_len(const umlh_handle_s* h) { return h->dp_diag ? 2 * h->L.n_head : h->L.n_head; }
 static inline long long msg_tail_off(const umlh_handle_s* h) { return msg_head_len(h) + h->L.n_proj; }
 static inline long long msg_len(const umlh_handle_s* h) { return msg_tail_off(h) + 2 + UMLH_N_SCALARS; }
@@ -508,7 +521,7 @@ int umlh_optimizer_step(int32_t optimizer, float* param, const float* grad, floa
     memset(&hy, 0, sizeof(hy));
     hy.lr = lr; hy.step = step;
     OptArgs o = make_opt(c, hy);
-    HIPCHK(umlh_launch_reduce_update(1, grad, 1, n, n, nullptr, param, m, v, &o, (hipStream_t)stream),
+    HIPCHK(umlh_launch_reduce_update(1, grad, 1, n, n, nullptr, param, m, v, &o, 0, 0, (hipStream_t)stream),
            "optimizer step");
     return UMLH_OK;
 }
@@ -1100,11 +1113,11 @@ static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_
     } else {
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
         HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, nullptr,
-                                         h->buf.w_head, h->buf.m_head, h->buf.v_head, &o, st), "update head");
+                                         h->buf.w_head, h->buf.m_head, h->buf.v_head, &o, 0, 0, st), "update head");
     }
     if (sp > 0)
         HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj, nullptr,
-                                         h->buf.w_proj, h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
+                                         h->buf.w_proj, h->buf.m_proj, h->buf.v_proj, &o, frozen_lo(h), frozen_hi(h), st), "update proj");
     mark(h, 5, st);
     return UMLH_OK;
 }
@@ -1513,7 +1526,7 @@ static int dp_reduce_head(umlh_handle_t h, const umlh_batch_t* img, const umlh_b
                                      nullptr, 32 * h->ctw * h->wc, &f, grads, nullptr, st), "reduce head");
     } else {
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
-        HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, nh, nh, grads, nullptr, nullptr, nullptr, &o, st), "reduce head");
+        HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, nh, nh, grads, nullptr, nullptr, nullptr, &o, 0, 0, st), "reduce head");
     }
     return UMLH_OK;
 }
@@ -1560,7 +1573,7 @@ static int grad_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_b
     if (h->cfg.has_proj) {
         float* gp = grads + msg_head_len(h);
         if (sp > 0)
-            HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj, gp, nullptr, nullptr, nullptr, &o, st),
+            HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_proj), sp, h->L.n_proj, h->L.n_proj, gp, nullptr, nullptr, nullptr, &o, 0, 0, st),
                    "reduce proj");
         else
             HIPCHK((int)hipMemsetAsync(gp, 0, sizeof(float) * h->L.n_proj, st), "zero proj grad");
@@ -1626,12 +1639,12 @@ static int apply_update_impl(umlh_handle_t h, const umlh_hyper_t* hy, float* sca
         h->shadow_fresh = bf;              // the next umlh_grad_step may trust it (see umlh_grad_step)
     } else {
         HIPCHK(umlh_launch_reduce_update(1, grads, 1, h->L.n_head, h->L.n_head, nullptr, h->buf.w_head, h->buf.m_head,
-                                         h->buf.v_head, &o, st), "update head");
+                                         h->buf.v_head, &o, 0, 0, st), "update head");
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
     }
     if (h->cfg.has_proj && h->global_rows_img > 0)
         HIPCHK(umlh_launch_reduce_update(1, grads + msg_head_len(h), 1, h->L.n_proj, h->L.n_proj, nullptr, h->buf.w_proj,
-                                         h->buf.m_proj, h->buf.v_proj, &o, st), "update proj");
+                                         h->buf.m_proj, h->buf.v_proj, &o, frozen_lo(h), frozen_hi(h), st), "update proj");
     return UMLH_OK;
 }
 

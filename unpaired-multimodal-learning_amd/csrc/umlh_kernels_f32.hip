@@ -863,9 +863,12 @@ template <int MODE>
 __global__ __launch_bounds__(256) void reduce_update(const float* __restrict__ slabs, int n_slabs,
                                                      long long slab_stride, long long n,
                                                      float* __restrict__ grad_out, float* __restrict__ p,
-                                                     float* __restrict__ m, float* __restrict__ v, OptArgs o) {
+                                                     float* __restrict__ m, float* __restrict__ v, OptArgs o,
+                                                     long long frozen_lo, long long frozen_hi) {
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
+    // elements [frozen_lo, frozen_hi) (multiples of 4) keep their value and moments: the constant row of an img_proj with bias
+    if (MODE == 1 && i >= frozen_lo && i < frozen_hi) return;
     if (i + 4 <= n && (slab_stride % 4 == 0)) {
         f32x4v gsum = {0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < n_slabs; ++s)
@@ -1274,16 +1277,17 @@ int umlh_f32_launch_gemm_enc(const GemmArgs* g, int ta, int tb, int splits, hipS
 }
 
 int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long long slab_stride, long long n,
-                              float* grad_out, float* p, float* m, float* v, const OptArgs* o,
-                              hipStream_t stream) {
+                              float* grad_out, float* p, float* m, float* v, const OptArgs* o, long long frozen_lo,
+                              long long frozen_hi, hipStream_t stream) {
     if (n <= 0) return 0;
+    if (frozen_lo < frozen_hi && (frozen_lo % 4 || frozen_hi % 4)) return (int)hipErrorInvalidValue;
     int blocks = (int)((n + 1023) / 1024);
     if (mode == 0)
         hipLaunchKernelGGL((reduce_update<0>), dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, n,
-                           grad_out, p, m, v, *o);
+                           grad_out, p, m, v, *o, frozen_lo, frozen_hi);
     else
         hipLaunchKernelGGL((reduce_update<1>), dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, n,
-                           grad_out, p, m, v, *o);
+                           grad_out, p, m, v, *o, frozen_lo, frozen_hi);
     return (int)hipGetLastError();
 }
 

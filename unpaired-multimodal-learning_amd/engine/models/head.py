@@ -12,8 +12,9 @@ In this build the backbone is the identity over PRE-EXTRACTED feature rows
     model.head.weight, model.img_proj, model.num_classes, model.shared_dim,
     model.extract_features, model.extract_raw_features, model.zero_shot_init(text_ds)
 
-``bias=True`` is supported for the linear heads (no img_proj): weight and bias are views of one packed tensor and the
-kernels see rows [x | 1 | 0...] (see ``_HeadBase._pack_head``).
+``bias=True``: weight and bias of a layer are views of one packed tensor and the
+kernels see rows [x | 1 | 0...] (see ``_HeadBase._pack_head``); with img_proj both layers carry their bias and one row of
+the packed projection is a frozen constant (``umlh_freeze_proj_row``).
 
 ``forward`` returns the logits tensors (computed by ``umlh_logits``); training
 goes through ``fused_engine(optimizer)`` -> ``HeadEngine.train_step`` which never
@@ -126,35 +127,49 @@ class _HeadBase(nn.Module):
     # The kernels run a bias-free head over rows [x | 1 | 0...] (HeadEngine ``bias_from``): ``head.weight`` and ``head.bias``
     # are VIEWS of one packed [C, d_aug] tensor (d_aug = d + 1 rounded up to 128: valid for both precision modes), so the
     # reference's parameter names, shapes, initialisation and state_dict keys stay as they are.
+    @staticmethod
+    def _pack_linear(lin, rows_aug=None):
+        """[out, in] weight + [out] bias of ``lin`` -> packed [rows, in_aug] = [weight | bias | 0...] (in_aug = in + 1 rounded up
+        to 128; ``rows_aug`` > out adds zero rows); weight and bias become views of it."""
+        w, b = lin.weight, lin.bias
+        out, d = w.shape
+        d_aug = (d + 1 + 127) // 128 * 128
+        packed = torch.zeros(rows_aug or out, d_aug, dtype=torch.float32, device=w.device)
+        packed[:out, :d] = w.data
+        packed[:out, d] = b.data
+        w.data = packed[:out, :d]
+        b.data = packed[:out, d]
+        return packed
+
     def _pack_head(self):
         if not getattr(self, "_bias", False) or not hasattr(self, "head"):
             return
-        w, b = self.head.weight, self.head.bias
-        C, d = w.shape
-        d_aug = (d + 1 + 127) // 128 * 128
-        packed = torch.zeros(C, d_aug, dtype=torch.float32, device=w.device)
-        packed[:, :d] = w.data
-        packed[:, d] = b.data
-        self._packed = packed
-        w.data = packed[:, :d]
-        b.data = packed[:, d]
+        self._packed = self._pack_linear(self.head)
+        self._packed_proj = None
+        if getattr(self, "img_proj", None) is not None:
+            # img_proj with bias: its output rows are [h | 1 | 0...] so that the head's bias column sees a 1 on projected image
+            # rows too -- row d_sh of the packed projection copies the ones column of the input (frozen: umlh_freeze_proj_row)
+            d_sh, d_img = self.img_proj.weight.shape
+            self._packed_proj = self._pack_linear(self.img_proj, rows_aug=self._packed.shape[1])
+            self._packed_proj[d_sh, d_img] = 1.0
 
-    def _packed_state(self, optimizer, opt_name):
-        """Optimizer moments of (weight, bias) as views of packed [C, d_aug] tensors (what the kernels update)."""
-        pk = getattr(optimizer, "_packed_head_state", None)
-        w, b = self.head.weight, self.head.bias
-        d = w.shape[1]
-        if pk is None or pk[0].shape != self._packed.shape or pk[0].device != self._packed.device:
+    def _packed_state(self, optimizer, opt_name, lin, packed, tag):
+        """Optimizer moments of (weight, bias) of ``lin`` as views of packed tensors shaped like ``packed`` (what the kernels update)."""
+        store = optimizer.__dict__.setdefault("_packed_state", {})
+        pk = store.get(tag)
+        w, b = lin.weight, lin.bias
+        out, d = w.shape
+        if pk is None or pk[0].shape != packed.shape or pk[0].device != packed.device:
             names = ["momentum_buffer"] if opt_name == "sgd" else ["exp_avg", "exp_avg_sq"]
-            pk = tuple(torch.zeros_like(self._packed) for _ in names)
+            pk = tuple(torch.zeros_like(packed) for _ in names)
             for t, nm in zip(pk, names):                     # adopt moments the optimizer may already hold (resumed state)
-                for p, view in ((w, t[:, :d]), (b, t[:, d])):
+                for p, view in ((w, t[:out, :d]), (b, t[:out, d])):
                     old = optimizer.state.get(p, {}).get(nm)
                     if old is not None:
                         view.copy_(old)
-            optimizer.state[w] = {nm: t[:, :d] for t, nm in zip(pk, names)}
-            optimizer.state[b] = {nm: t[:, d] for t, nm in zip(pk, names)}
-            optimizer._packed_head_state = pk
+            optimizer.state[w] = {nm: t[:out, :d] for t, nm in zip(pk, names)}
+            optimizer.state[b] = {nm: t[:out, d] for t, nm in zip(pk, names)}
+            store[tag] = pk
         return pk
 
     # ---- fused path ------------------------------------------------------------------
@@ -181,16 +196,25 @@ class _HeadBase(nn.Module):
                                                                          eps=1e-8, momentum=0.9)
         if self._bias:
             d_aug = self._packed.shape[1]
-            eng = umlh.HeadEngine(d_aug, d_aug, self.num_classes, has_proj=False, learnable_temp=self._learnable_temp,
-                                  optimizer=opt_name, weight_decay=g["weight_decay"], betas=g["betas"], eps=g["eps"],
-                                  momentum=g["momentum"], max_rows_img=max_rows_img, max_rows_txt=max_rows_txt,
-                                  precision=precision, device=dev, bias_from=self.shared_dim)
+            proj = self._packed_proj is not None
+            eng = umlh.HeadEngine(self._packed_proj.shape[1] if proj else d_aug, d_aug, self.num_classes, has_proj=proj,
+                                  learnable_temp=self._learnable_temp, optimizer=opt_name, weight_decay=g["weight_decay"],
+                                  betas=g["betas"], eps=g["eps"], momentum=g["momentum"], max_rows_img=max_rows_img,
+                                  max_rows_txt=max_rows_txt, precision=precision, device=dev,
+                                  bias_from=(self.img_proj.weight.shape[1], self.shared_dim) if proj else self.shared_dim)
             bind = dict(w_head=self._packed, scales=self._scales)
+            if proj:
+                bind["w_proj"] = self._packed_proj
             if optimizer is not None:
-                pk = self._packed_state(optimizer, opt_name)
+                pk = self._packed_state(optimizer, opt_name, self.head, self._packed, "head")
                 bind["m_head"] = pk[0]
                 if len(pk) > 1:
                     bind["v_head"] = pk[1]
+                if proj:
+                    pk = self._packed_state(optimizer, opt_name, self.img_proj, self._packed_proj, "proj")
+                    bind["m_proj"] = pk[0]
+                    if len(pk) > 1:
+                        bind["v_proj"] = pk[1]
             eng.rebind(**bind)
             if optimizer is not None and self._learnable_temp:
                 raise NotImplementedError("bias=True with learnable_temp: not wired (the reference never builds it)")
@@ -285,11 +309,7 @@ class UML(_HeadBase):
         # parameter creation order == reference (img_proj, head, img_scale, txt_scale): the
         # nn.Linear initialisers consume the global RNG identically (seed parity)
         if text_indim > 0:
-            if bias:
-                # the head's bias needs a constant-1 column in the PROJECTED rows: a frozen row of img_proj the optimizer
-                # kernels would have to skip -- not built (the reference never constructs bias=True: finetune.py:338,344,346)
-                raise NotImplementedError("bias=True together with img_proj (text_indim > 0) is not supported")
-            self.img_proj = nn.Linear(backbone.num_features, text_indim, bias=False)
+            self.img_proj = nn.Linear(backbone.num_features, text_indim, bias=bool(bias))
             self.shared_dim = text_indim
         self.head = nn.Linear(self.shared_dim, num_classes, bias=bool(bias))
         if learnable_temp:
@@ -322,7 +342,8 @@ class UML(_HeadBase):
         import umlh
         feats = feats.to(torch.float32).contiguous()
         dummy = torch.zeros(feats.shape[0], dtype=torch.int64, device=feats.device)
-        return self._infer_engine(feats.shape[0]).project(umlh.RowBatch(feats, dummy))
+        h = self._infer_engine(feats.shape[0]).project(umlh.RowBatch(feats, dummy))
+        return h[:, :self.shared_dim].contiguous() if self._bias else h      # (the packed projection appends [1 | 0...])
 
 
 class UMLClip(_HeadBase):

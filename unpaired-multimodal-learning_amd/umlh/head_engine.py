@@ -48,11 +48,16 @@ class HeadEngine:
                  learnable_temp: bool = False, optimizer: str = "adamw", weight_decay: float = 0.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9,
                  max_rows_img: int = 4096, max_rows_txt: int = 4096, precision: str = "fp32",
-                 device="cuda:0", bias_from: Optional[int] = None):
+                 device="cuda:0", bias_from=None):
         """``bias_from = d``: a linear head WITH bias (engine/models/head.py:65,68 ``bias=True``) over d-wide features, run
         as a bias-free head over ``d_shared``-wide rows [x | 1 | 0...]: column d of every feature row is 1 (appended here, cached
         per table), column d of ``w_head`` is the bias, columns beyond are zero padding that stays zero (zero gradient; AdamW's
-        decay of 0 is 0).  Same logits ``x W^T + b``, same gradients and optimizer recurrences for weight and bias."""
+        decay of 0 is 0).  Same logits ``x W^T + b``, same gradients and optimizer recurrences for weight and bias.
+        ``bias_from = (d_img, d_sh)`` with ``has_proj``: the 2-layer head with both biases -- image rows widen to ``d_img``
+        columns with their 1 at column d_img, text rows to ``d_shared`` with their 1 at column d_sh; column d_img of ``w_proj``
+        rows < d_sh is img_proj's bias, and row d_sh of ``w_proj`` is the constant row that copies the ones column into the
+        projected rows (so that column d_sh of ``w_head`` acts as the head's bias on both modalities): the caller writes it
+        (1 at column d_img) and the optimizer leaves it alone (``umlh_freeze_proj_row``)."""
         if optimizer not in OPT_IDS:   # engine/optimizer/optim.py:22
             raise AssertionError(f"Optimizer {optimizer} not found; available optimizers = {list(OPT_IDS)}")
         self.lib = _lib.load_library()
@@ -74,10 +79,20 @@ class HeadEngine:
         self.has_proj, self.learnable_temp, self.optimizer = bool(has_proj), bool(learnable_temp), optimizer
         self.precision = precision
         self.d_img, self.d_shared, self.num_classes = d_img, d_shared, num_classes
-        self.bias_from = None if bias_from is None else int(bias_from)
-        if self.bias_from is not None and (has_proj or d_img != d_shared or not 0 < self.bias_from < d_shared):
-            raise UmlhError("bias_from: linear heads only (no img_proj), with d_img == d_shared > bias_from")
-        self._aug_cache = {}                 # (data_ptr, rows, version) -> (fp32 augmented rows, bf16 shadow or None)
+        self.bias_from = None
+        self._from_img = self._from_txt = None       # user-visible widths of image / text rows of a head with bias
+        if bias_from is not None:
+            if has_proj:
+                self._from_img, self._from_txt = (int(v) for v in bias_from)
+                if not (0 < self._from_img < d_img and 0 < self._from_txt < d_shared):
+                    raise UmlhError("bias_from: (d_img, d_sh) must leave room for the ones column in both widths")
+                check(self.lib.umlh_freeze_proj_row(self.handle, self._from_txt), "umlh_freeze_proj_row")
+            else:
+                self._from_img = self._from_txt = int(bias_from)
+                if d_img != d_shared or not 0 < self._from_txt < d_shared:
+                    raise UmlhError("bias_from: a linear head needs d_img == d_shared > bias_from")
+            self.bias_from = bias_from
+        self._aug_cache = {}                 # (data_ptr, rows, version, width) -> (fp32 augmented rows, bf16 shadow or None)
         self.w_head = torch.zeros(num_classes, d_shared, **f32)
         self.m_head = torch.zeros_like(self.w_head)
         self.v_head = torch.zeros_like(self.w_head)
@@ -124,18 +139,28 @@ class HeadEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _augment(self, f: torch.Tensor, want16: bool):
-        """[N, d] feature rows -> ([N, d_shared] rows [x | 1 | 0...], bf16 shadow or None) for a head with bias.  Tables are
-        converted once (cached by address, row count and in-place version); rows that already have the engine's width
-        pass through."""
-        if self.bias_from is None or f.dim() != 2 or f.shape[1] != self.bias_from:
+    def _from_width(self, f, dim):
+        """User-visible width of rows headed for a ``dim``-wide operand of a head with bias, or None (no bias / rows that
+        already have the engine's width)."""
+        if self.bias_from is None or f.dim() != 2:
+            return None
+        for width, frm in ((self.d_img, self._from_img), (self.d_shared, self._from_txt)):
+            if dim == width and f.shape[1] == frm:
+                return frm
+        return None
+
+    def _augment(self, f: torch.Tensor, dim: int, want16: bool):
+        """[N, d] feature rows -> ([N, dim] rows [x | 1 | 0...], bf16 shadow or None) for a head with bias.  Tables are
+        converted once (cached by address, row count and in-place version)."""
+        frm = self._from_width(f, dim)
+        if frm is None:
             return f, None
-        key = (f.data_ptr(), int(f.shape[0]), int(f._version))
+        key = (f.data_ptr(), int(f.shape[0]), int(f._version), int(dim))
         hit = self._aug_cache.pop(key, None)
         if hit is None:
-            a = torch.zeros(f.shape[0], self.d_shared, dtype=torch.float32, device=f.device)
-            a[:, :self.bias_from] = f
-            a[:, self.bias_from] = 1.0
+            a = torch.zeros(f.shape[0], dim, dtype=torch.float32, device=f.device)
+            a[:, :frm] = f
+            a[:, frm] = 1.0
             hit = (a, None)
         if want16 and hit[1] is None:
             hit = (hit[0], to_bf16(hit[0]))
@@ -153,10 +178,10 @@ class HeadEngine:
             return Batch(None, None, None, 0, int(b.global_rows), None) if b.global_rows else None
         f, y = b.feats, b.labels
         f16_aug = None
-        if self.bias_from is not None and f.dim() == 2 and f.shape[1] == self.bias_from:
+        if self._from_width(f, dim) is not None:
             if f.dtype != torch.float32 or not f.is_contiguous():
                 raise UmlhError(f"features must be contiguous fp32, got {f.dtype} {tuple(f.shape)}")
-            f, f16_aug = self._augment(f, self.precision == "bf16")
+            f, f16_aug = self._augment(f, dim, self.precision == "bf16")
         if f.dtype != torch.float32 or not f.is_contiguous() or f.dim() != 2 or f.shape[1] != dim:
             raise UmlhError(f"features must be contiguous fp32 [N,{dim}], got {f.dtype} {tuple(f.shape)}")
         if y.dtype != torch.int64 or not y.is_contiguous():
@@ -230,8 +255,8 @@ class HeadEngine:
             return None, None
         f, y = table[0], table[1]
         f16 = table[2] if len(table) > 2 else None
-        if self.bias_from is not None and f.dim() == 2 and f.shape[1] == self.bias_from and f.dtype == torch.float32 and f.is_contiguous():
-            f, f16 = self._augment(f, self.precision == "bf16")
+        if self._from_width(f, dim) is not None and f.dtype == torch.float32 and f.is_contiguous():
+            f, f16 = self._augment(f, dim, self.precision == "bf16")
         if f.dtype != torch.float32 or not f.is_contiguous() or f.shape[1] != dim or y.dtype != torch.int64:
             raise UmlhError("train_steps: table must be contiguous fp32 [N,dim] + int64 labels")
         if self.precision == "bf16" and (f16 is None or f16.dtype != torch.bfloat16 or f16.shape != f.shape):
