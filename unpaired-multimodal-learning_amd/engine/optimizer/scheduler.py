@@ -55,8 +55,22 @@ class StepLR:
         return list(self._last_lr)
 
     def lr_table(self, n, start=None):
+        """lr_at(k0 .. k0+n-1) as a list.  The post-warm-up part is evaluated as one vector (same expression, double
+        precision; a sweep asks for ~10^5 values): a value may differ from ``lr_at`` in its last bit where numpy's cos and
+        math.cos round differently, far below the float32 the kernels take it in."""
         k0 = self.last_epoch if start is None else start
-        return [self.lr_at(k0 + i, self.base_lrs[0]) for i in range(n)]
+        base = self.base_lrs[0]
+        head = [self.lr_at(k, base) for k in range(k0, min(k0 + n, self.warmup_iter))]
+        m = n - len(head)
+        if m <= 0:
+            return head
+        import numpy as np
+        t = np.arange(k0 + len(head) - self.warmup_iter, k0 + n - self.warmup_iter, dtype=np.float64)
+        if self.kind == "cosine":
+            tail = base * (1.0 + np.cos(np.pi * t / self.max_iter)) / 2.0
+        else:
+            tail = base * (1.0 - t / self.max_iter)
+        return head + tail.tolist()
 
 
 def build_lr_scheduler(optimizer, lr_scheduler, warmup_iter, max_iter, warmup_type=None, warmup_lr=None,

@@ -262,28 +262,27 @@ class HeadEngine:
         if self.precision == "bf16" and (f16 is None or f16.dtype != torch.bfloat16 or f16.shape != f.shape):
             raise UmlhError("train_steps: bf16 engine needs the table's bf16 shadow")
         # an entry is one step's index vector, or (index slice, [sizes]) covering several consecutive steps
+        import numpy as np
         parts, sizes = [], []
         for b in batches:
             if isinstance(b, tuple):
                 parts.append(b[0])
-                sizes.extend(int(z) for z in b[1])
+                sizes.extend(b[1])
             else:
                 parts.append(b)
-                sizes.append(int(b.numel()))
+                sizes.append(b.numel())
         if len(sizes) != n:
             raise UmlhError("train_steps: one index vector per step required")
-        if max(sizes) > cap:
-            raise UmlhError(f"train_steps: batch of {max(sizes)} rows exceeds capacity {cap}")
+        offs_np = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.asarray(sizes, dtype=np.int32), out=offs_np[1:])
+        largest = int(np.diff(offs_np).max()) if n else 0
+        if largest > cap:
+            raise UmlhError(f"train_steps: batch of {largest} rows exceeds capacity {cap}")
         idx = torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
-        if idx.numel() != sum(sizes):
+        if idx.numel() != int(offs_np[n]):
             raise UmlhError("train_steps: index slices do not match their batch sizes")
-        offs = (C.c_int32 * (n + 1))()
-        acc = 0
-        for k, sz in enumerate(sizes):
-            offs[k] = acc
-            acc += sz
-        offs[n] = acc
-        keep = (f, y, f16, idx, offs)
+        offs = offs_np.ctypes.data_as(C.POINTER(C.c_int32))
+        keep = (f, y, f16, idx, offs_np)
         return Stream(_ptr(f), _ptr(f16), _ptr(y), _ptr(idx), offs), keep
 
     def train_steps(self, img_table, img_index_batches, txt_table, txt_index_batches, lrs, first_step: int,
