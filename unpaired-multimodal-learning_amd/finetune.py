@@ -169,6 +169,30 @@ def _draw_block(img_src, txt_src, n):
     return bi, bt
 
 
+def _rewind_point(img_src, txt_src, optimizer, scheduler):
+    """Everything a training block advances besides the weights, captured before the block is drawn: loader positions, the
+    RNG streams the loaders draw their epoch seeds from, optimizer moments and counters, the scheduler's epoch."""
+    gens = []
+    for src in (img_src, txt_src):
+        g = getattr(src.loader, "generator", None) if src is not None else None
+        if src is not None and all(g is not q for q, _ in gens):
+            gens.append((g, g.get_state() if g is not None else torch.get_rng_state()))
+    moments = [(t, t.clone()) for st in optimizer.state.values() for t in st.values() if torch.is_tensor(t)]
+    return {"src": [(src, src.save()) for src in (img_src, txt_src) if src is not None], "gens": gens, "moments": moments,
+            "step_count": optimizer.step_count, "epoch": scheduler.last_epoch}
+
+
+def _rewind(r, optimizer, scheduler):
+    for src, st in r["src"]:
+        src.restore(st)
+    for g, st in r["gens"]:
+        g.set_state(st) if g is not None else torch.set_rng_state(st)
+    for t, old in r["moments"]:
+        t.copy_(old)
+    optimizer.step_count = r["step_count"]
+    scheduler.step(r["epoch"])
+
+
 def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, scheduler, device="cuda",
           max_iters=1000, alpha=1.0, eval_freq=EVAL_FREQ, patience=5, capture_features_during_training=False,
           features_pth="./", args=None, logger=None, precision="fp32", diagnostics=None):
@@ -237,25 +261,10 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
         return False
 
     def rewind_point():
-        """Everything a training block advances besides the weights, captured before the block is drawn."""
-        gens = []
-        for src in (img_src, txt_src):
-            g = getattr(src.loader, "generator", None) if src is not None else None
-            if src is not None and all(g is not q for q, _ in gens):
-                gens.append((g, g.get_state() if g is not None else torch.get_rng_state()))
-        moments = [(t, t.clone()) for st in optimizer.state.values() for t in st.values() if torch.is_tensor(t)]
-        return {"src": [(src, src.save()) for src in (img_src, txt_src) if src is not None], "gens": gens, "moments": moments,
-                "step_count": optimizer.step_count, "epoch": scheduler.last_epoch}
+        return _rewind_point(img_src, txt_src, optimizer, scheduler)
 
     def rewind(r):
-        for src, st in r["src"]:
-            src.restore(st)
-        for g, st in r["gens"]:
-            g.set_state(st) if g is not None else torch.set_rng_state(st)
-        for t, old in r["moments"]:
-            t.copy_(old)
-        optimizer.step_count = r["step_count"]
-        scheduler.step(r["epoch"])
+        _rewind(r, optimizer, scheduler)
 
     pending = None            # evaluation whose results have not been read yet (blockwise runs only)
     stopped = False
@@ -350,16 +359,49 @@ def train_grouped(runs, device="cuda", eval_freq=EVAL_FREQ, precision="fp32"):
                        scalars=torch.zeros(r["max_iters"], umlh.N_SCALARS, dtype=torch.float32, device=dev),
                        out={"iter": None, "val_acc": None, "model": None, "val_classwise": None, "val_loss": None,
                             "model_records": []}))
-    while any(h["live"] for h in st):
+    # Evaluation results are read one round LATE, as in train(): a round enqueues the next block of every live head first and
+    # only then waits for the previous round's evaluation copy, so the GPU runs while the host reads, decides and prepares.
+    # A head whose late result is an early stop has its extra block rewound (loader / RNG / optimizer state; the weights are
+    # replaced by its best snapshot at the end).  Needs private loader generators (a generator shared between heads cannot be
+    # rewound for one of them): otherwise every round reads its own evaluation before the next block is drawn.
+    def private(h):
+        return all(src is None or getattr(src.loader, "generator", None) is not None for src in (h["img_src"], h["txt_src"]))
+    pipelined = all(private(h) for h in st)
+
+    def settle(due, at, handle):
+        """Bookkeeping of the evaluations `handle` holds (head h evaluated at iteration at[k]): best snapshot, patience; a head
+        that stops is rewound to its evaluation point if a block was enqueued for it since."""
+        res, _ = validate_many_end(handle)
+        k = 0
+        for h, i_eval in zip(due, at):
+            val_loss, val_acc = res[k]
+            k += 2 if h.get("test_loader") is not None else 1
+            out = h["out"]
+            if out["val_acc"] is None or val_acc > out["val_acc"]:
+                out.update(iter=i_eval, val_acc=val_acc, val_loss=val_loss, model=h.pop("snap"))
+                h["no_improve"] = 0
+            else:
+                h["no_improve"] += 1
+                h.pop("snap")
+            if h["no_improve"] >= h["patience"]:                    # early stopping of this head at i_eval
+                if h["live"] and h.get("back") is not None:         # ... one block ago: take that block back
+                    _rewind(h["back"], h["optimizer"], h["scheduler"])
+                h["live"] = False
+                h["i"] = h["last_i"] = i_eval
+
+    pending = None                      # (due heads, their evaluation iterations, validate_many_begin handle)
+    while any(h["live"] for h in st) or pending is not None:
         # ---- one block per live head: all steps up to and including its next evaluation point ----
         by_n = {}
+        awaited = {id(h) for h in pending[0]} if pending is not None else set()
         for h in st:
             if not h["live"]:
                 continue
+            opt, sch = h["optimizer"], h["scheduler"]
+            h["back"] = _rewind_point(h["img_src"], h["txt_src"], opt, sch) if id(h) in awaited else None
             i_end = _block_end(h["i"], h["max_iters"], eval_freq)
             n = i_end - h["i"] + 1
             bi, bt = _draw_block(h["img_src"], h["txt_src"], n)
-            opt, sch = h["optimizer"], h["scheduler"]
             job = dict(engine=h["engine"], img_table=h["img_src"].table(precision) if h["img_src"] else None, img_index_batches=bi,
                        txt_table=h["txt_src"].table(precision) if h["txt_src"] else None, txt_index_batches=bt,
                        lrs=sch.lr_table(n), first_step=opt.step_count + 1, alpha=h["alpha"], img_alpha=1.0,
@@ -370,6 +412,10 @@ def train_grouped(runs, device="cuda", eval_freq=EVAL_FREQ, precision="fp32"):
             h["i"] = h["last_i"] = i_end
         for n, jobs in by_n.items():
             umlh.train_steps_grouped(jobs, n)
+        # ---- the previous round's evaluations (the blocks above are already running) ----
+        if pending is not None:
+            p, pending = pending, None
+            settle(*p)
         # ---- evaluation points (every live head sits on one, or on its final iteration) ----
         due = [h for h in st if h["live"] and h["i"] % eval_freq == 0]
         if due:
@@ -381,21 +427,14 @@ def train_grouped(runs, device="cuda", eval_freq=EVAL_FREQ, precision="fp32"):
                 if h.get("test_loader") is not None:
                     pairs.append((h["model"], h["test_loader"]))
                 extra.append(h["scalars"][h["i"]])
-            res, _ = validate_many(pairs, extra=extra)
-            k = 0
+            handle = validate_many_begin(pairs, extra=extra)
             for h in due:
                 h["model"].train()
-                val_loss, val_acc = res[k]
-                k += 2 if h.get("test_loader") is not None else 1
-                out = h["out"]
-                if out["val_acc"] is None or val_acc > out["val_acc"]:
-                    out.update(iter=h["i"], val_acc=val_acc, val_loss=val_loss, model=h.pop("snap"))
-                    h["no_improve"] = 0
-                else:
-                    h["no_improve"] += 1
-                    h.pop("snap")
-                if h["no_improve"] >= h["patience"]:
-                    h["live"] = False                               # early stopping of this head
+                h["back"] = None
+            pending = (due, [h["i"] for h in due], handle)
+            if not pipelined:                                       # shared generators: decide before the next block is drawn
+                p, pending = pending, None
+                settle(*p)
         for h in st:
             if h["live"]:
                 h["i"] += 1
