@@ -209,3 +209,59 @@ def test_bias_head_keeps_reference_parameter_surface():
     assert tuple(p2.img_proj.weight.shape) == (64, 96) and tuple(p2.img_proj.bias.shape) == (64,)
     assert float(p2._packed_proj[64, 96]) == 1.0 and float(p2._packed_proj[64].sum()) == 1.0
     assert torch.equal(p2._packed_proj[:64, 96], p2.img_proj.bias.data) and float(p2._packed_proj[65:].abs().max()) == 0.0
+
+
+def test_encoder_plan_pool_leases_and_eviction():
+    """multibench.encoder's plan pool (host logic only, fake plans): a busy plan is never handed out twice, an idle one is
+    reused, releasing is tied to the lease's lifetime, and least-recently-used idle configurations are dropped."""
+    import gc
+    from multibench import encoder as E
+
+    class Fake:
+        made = 0
+
+        def __init__(self):
+            Fake.made += 1
+            self.busy = False
+    saved = dict(E._PLANS)
+    E._PLANS.clear()
+    try:
+        a = E._lease_plan("k", Fake)
+        b = E._lease_plan("k", Fake)
+        assert a.plan is not b.plan and a.plan.busy and b.plan.busy and Fake.made == 2
+        pa = a.plan
+        del a
+        gc.collect()
+        assert not pa.busy
+        c = E._lease_plan("k", Fake)
+        assert c.plan is pa and Fake.made == 2
+        del b, c
+        gc.collect()
+        held = E._lease_plan("held", Fake)                       # a busy configuration survives eviction
+        for i in range(E._PLAN_KEYS_MAX + 5):
+            E._lease_plan(("cfg", i), Fake)
+        assert len(E._PLANS) <= E._PLAN_KEYS_MAX + 1 and "held" in E._PLANS and "k" not in E._PLANS
+        del held
+    finally:
+        E._PLANS.clear()
+        E._PLANS.update(saved)
+
+
+def test_lr_table_equals_stepwise_schedule():
+    """StepLR.lr_table (vector expression) == lr_at step by step (within one ulp of double) for every schedule / warm-up pair,
+    across the warm-up boundary and past max_iter."""
+    import numpy as np
+    from engine.optimizer.scheduler import StepLR
+
+    class Opt:
+        def __init__(self):
+            self.param_groups = [{"lr": 1e-3}]
+    for kind in ("cosine", "linear"):
+        for wt, wi in (("linear", 50), ("constant", 7), (None, 0)):
+            s = StepLR(Opt(), kind, 300, warmup_iter=wi, warmup_type=wt, warmup_lr=1e-5)
+            assert s.base_lrs == [1e-3]
+            for start, n in ((0, 120), (40, 30), (wi, 1), (290, 40)):
+                tab = np.asarray(s.lr_table(n, start=start))
+                ref = np.asarray([s.lr_at(start + i, 1e-3) for i in range(n)])
+                assert tab.shape == ref.shape
+                np.testing.assert_allclose(tab, ref, rtol=4e-16, atol=1e-22)
