@@ -106,7 +106,12 @@ __device__ __forceinline__ s16x4m pack_bf16x4(float a, float b, float c, float d
     return __builtin_bit_cast(s16x4m, w);
 }
 
-template <int NCH, int CW>
+// RES (bf16 operand mode, 128-wide chunks, d <= 640): the step's feature rows stay in LDS as bf16 -- NCH + 1 chunk regions of
+// 64 rows x 128 columns (16 KB each) in a ring -- so the backward re-reads them instead of staging every chunk a second
+// time: half the global loads, LDS stores and staging instructions of a step, and no barriers between forward chunks.
+// Region of chunk c of step k: (base_k + c) mod (NCH + 1), base_{k+1} = base_k + NCH: the next step's chunk 0 goes to the one
+// region this step does not use, its chunk c >= 1 to the region this step's chunk c-1 leaves after its backward position.
+template <int NCH, int CW, bool RES = false>
 struct MicroCfg {
     static constexpr int D = NCH * CW;
     static constexpr int LDW = D + 8;                       // W slice row stride: b128 reads of 16 rows conflict-free (LDW % 64 == 8)
@@ -114,21 +119,25 @@ struct MicroCfg {
     static constexpr int SM = SLOTS - 1 < 15 ? SLOTS - 1 : 15;   // swizzle mask
     static constexpr int DPW = CW / 16;                     // 16-byte pieces per lane per chunk (64 rows x CW floats over 256 lanes)
     static constexpr int XBYTES = MROWS * CW * 4;
+    static constexpr int XTOTAL = RES ? (NCH + 1) * MROWS * CW * 2 : 2 * XBYTES;
     static constexpr int WBYTES = CS * LDW * 4;
     static constexpr int MISC = CS * LDZ * 4 + 2 * MROWS * 8 + 2 * MROWS * 4 + 4 * MROWS * 5 * 4 + 64 * 4;
-    static constexpr int SMEM = WBYTES + 2 * XBYTES + MISC;
+    static constexpr int SMEM = WBYTES + XTOTAL + MISC;
     static constexpr int U = CW >= 64 ? CW / 64 : 1;        // 64-column blocks per chunk in the dW phase
     static constexpr int NP = 2 * NCH;                      // chunk positions of a step: NCH forward, NCH backward
 };
 
 template <int NCH, int CW, bool BF>
 __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* __restrict__ heads, int n_heads, int n_steps) {
-    using K = MicroCfg<NCH, CW>;
+    constexpr bool RES = BF && CW == 128 && NCH <= 5;
+    using K = MicroCfg<NCH, CW, RES>;
     constexpr int D = K::D, LDW = K::LDW, SM = K::SM, DPW = K::DPW, U = K::U, NP = K::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Wl = reinterpret_cast<float*>(smem);                                    // [CS][LDW]
-    float* Xb = reinterpret_cast<float*>(smem + K::WBYTES);                        // [2][64][CW]
-    float* dzT = reinterpret_cast<float*>(smem + K::WBYTES + 2 * K::XBYTES);       // [CS][LDZ]
+    float* Xb = reinterpret_cast<float*>(smem + K::WBYTES);                        // [2][64][CW]        (RES: unused)
+    unsigned short* Xh = reinterpret_cast<unsigned short*>(smem + K::WBYTES);      // RES: [NCH + 1][64][CW] bf16
+    constexpr int RGN = MROWS * CW;                                                // elements of a chunk region
+    float* dzT = reinterpret_cast<float*>(smem + K::WBYTES + K::XTOTAL);           // [CS][LDZ]
     unsigned long long* rowbase = reinterpret_cast<unsigned long long*>(dzT + CS * LDZ);   // [2][64] byte address of the row
     int* labs = reinterpret_cast<int*>(rowbase + 2 * MROWS);                        // [2][64]
     float* red = reinterpret_cast<float*>(labs + 2 * MROWS);                        // [4 parts][64][5]
@@ -240,10 +249,23 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
 #pragma unroll
         for (int i = 0; i < DPW; ++i) *reinterpret_cast<f32x4m*>(Xb + buf * (MROWS * CW) + doff[i]) = xr[i];
     };
-    // prologue: position 0 of step 0 into buffer 0, position 1 into the registers
-    xload(rowp_cur, 0);
-    xstore(0);
-    xload(rowp_cur, 1 % NCH);
+    auto xstore_res = [&](int region) {                    // the staged chunk, rounded to bf16, into a region of the ring
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            *reinterpret_cast<s16x4m*>(Xh + region * RGN + doff[i]) = pack_bf16x4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
+    };
+    int rbase = 0;                                          // RES: region of this step's chunk 0
+    auto region_of = [&](int base, int c) -> int { int r = base + c; return r > NCH ? r - (NCH + 1) : r; };
+    if (RES) {
+        // prologue: every chunk of step 0 into its region
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { xload(rowp_cur, c); xstore_res(c); }
+    } else {
+        // prologue: position 0 of step 0 into buffer 0, position 1 into the registers
+        xload(rowp_cur, 0);
+        xstore(0);
+        xload(rowp_cur, 1 % NCH);
+    }
     wg_barrier();
 
     constexpr int NOPT = (int)(sizeof(OptArgs) / 4);
@@ -295,9 +317,19 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
         // Position p of the step (chunk p is complete in LDS buffer p & 1): write chunk p+1 (in the registers) to the other
         // buffer -- its last readers passed the barrier that ended position p-1 -- and request chunk p+2.
         auto stage = [&](int p) {
-            if (p + 1 < NP || more) xstore((p + 1) & 1);
-            if (p + 2 < NP) xload(rowp_cur, (p + 2) % NCH);
-            else if (more) xload(rowp_nxt, (p + 2 - NP) % NCH);
+            if (RES) {
+                // only the NEXT step's chunks move: chunk c is requested at position NCH + c - 1 and written, one position
+                // later, to the region this step's chunk c - 1 has just left (chunk 0: to the spare region)
+                if (more) {
+                    const int nb = region_of(rbase, NCH);   // base of the next step
+                    if (p >= NCH) xstore_res(region_of(nb, p - NCH));
+                    if (p >= NCH - 1 && p + 1 < NP) xload(rowp_nxt, p + 1 - NCH);
+                }
+            } else {
+                if (p + 1 < NP || more) xstore((p + 1) & 1);
+                if (p + 2 < NP) xload(rowp_cur, (p + 2) % NCH);
+                else if (more) xload(rowp_nxt, (p + 2 - NP) % NCH);
+            }
             __builtin_amdgcn_sched_barrier(0);              // the requests stay ahead of the position's MFMAs
         };
 
@@ -308,6 +340,36 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             stage(c);
             MSTAMP(7);
             constexpr int T = CW / 16;
+            if (RES) {
+                if (tile_live) {
+                    const unsigned short* xrow = Xh + region_of(rbase, c) * RGN + (16 * wave + s16) * CW;
+                    const float* wrow = Wl + s16 * LDW + c * CW + 4 * g;
+                    constexpr int T2 = CW / 16;
+                    f32x4m a4[3];
+                    s16x4m b4[3];
+                    auto ld = [&](int t, int sl) {
+                        a4[sl] = *reinterpret_cast<const f32x4m*>(wrow + 16 * t);
+                        b4[sl] = *reinterpret_cast<const s16x4m*>(xrow + 4 * ((4 * t + g) ^ (s16 & SM)));
+                    };
+                    ld(0, 0);
+                    ld(1, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < T2; ++t) {
+                        if (t + 2 < T2) ld(t + 2, (t + 2) % 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int sl = t % 3;
+                        const s16x4m pa = pack_bf16x4(a4[sl][0], a4[sl][1], a4[sl][2], a4[sl][3]);
+                        if (t & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, b4[sl], acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, b4[sl], acc0, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                MSTAMP(1);
+                if (c == NCH - 1) wg_barrier();             // (one barrier for the whole forward: the chunks are resident)
+                MSTAMP(8);
+                continue;
+            }
             if (tile_live) {
                 const float* xrow = Xb + (c & 1) * (MROWS * CW) + (16 * wave + s16) * CW;
                 const float* wrow = Wl + s16 * LDW + c * CW + 4 * g;
@@ -540,20 +602,23 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             stage(NCH + c);
             MSTAMP(10);
             const float* xb = Xb + ((NCH + c) & 1) * (MROWS * CW);
+            const unsigned short* xh = Xh + (RES ? region_of(rbase, c) : 0) * RGN;
             f32x4m dacc[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) dacc[u] = f32x4m{0.f, 0.f, 0.f, 0.f};
             // all B operands of the chunk first (16 U independent LDS reads in flight), then the MFMA chains.  Lane s16 of
             // wave w owns column 64u + 16w + s16: consecutive lanes read consecutive dwords of a row (the slot swizzle
-            // keeps the four rows of a k-step on different banks).
+            // keeps the four rows of a k-step on different banks).  RES: the same elements as bf16 halves of the resident rows.
             float bq[16][U];
+            unsigned short bh[16][U];
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const int row = 4 * m + g;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int col = colok ? 64 * u + colw : CW - 1;
-                    bq[m][u] = xb[row * CW + 4 * ((col >> 2) ^ (row & SM)) + (col & 3)];
+                    const int at = row * CW + 4 * ((col >> 2) ^ (row & SM)) + (col & 3);
+                    if (RES) bh[m][u] = xh[at]; else bq[m][u] = xb[at];
                 }
             }
             float pw[U][4];
@@ -564,9 +629,11 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
                 for (int mm = 0; mm < 4; ++mm) {
                     const s16x4m pa = pack_bf16x4(af[4 * mm], af[4 * mm + 1], af[4 * mm + 2], af[4 * mm + 3]);
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        dacc[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pack_bf16x4(bq[4 * mm][u], bq[4 * mm + 1][u], bq[4 * mm + 2][u], bq[4 * mm + 3][u]),
-                                                                            dacc[u], 0, 0, 0);
+                    for (int u = 0; u < U; ++u) {
+                        const s16x4m pb = RES ? s16x4m{(short)bh[4 * mm][u], (short)bh[4 * mm + 1][u], (short)bh[4 * mm + 2][u], (short)bh[4 * mm + 3][u]}
+                                              : pack_bf16x4(bq[4 * mm][u], bq[4 * mm + 1][u], bq[4 * mm + 2][u], bq[4 * mm + 3][u]);
+                        dacc[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pb, dacc[u], 0, 0, 0);
+                    }
                 }
             } else {
 #pragma unroll
@@ -603,6 +670,7 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             else upds(std::integral_constant<int, UMLH_OPT_SGD>{});
         }
         // advance: the next step's row pointers become current, the offsets window moves on
+        if (RES) rbase = region_of(rbase, NCH);
 #pragma unroll
         for (int i = 0; i < DPW; ++i) rowp_cur[i] = rowp_nxt[i];
 #pragma unroll
@@ -641,7 +709,7 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
 
 template <int NCH, int CW, bool BF>
 int launch_one(const UmlhMicroHead* heads, int n_heads, int n_steps, int grid, hipStream_t st) {
-    using K = MicroCfg<NCH, CW>;
+    using K = MicroCfg<NCH, CW, BF && CW == 128 && NCH <= 5>;
     static unsigned long long attr_done = 0;               // bit d: done on device d
     int dev = 0;
     (void)hipGetDevice(&dev);
