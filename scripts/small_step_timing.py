@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Wall time of cfg1-shaped (batch 32+32, C=100, d=512) fused steps, enqueued 100 at a time."""
+"""Wall time of cfg1-shaped (batch 32+32, C=100, d=512) fused steps, enqueued 100 at a time.
+small_step_timing.py [batch] [fp32|bf16] [reps] [d] [C]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "unpaired-multimodal-learning_amd"))
 import torch
 import umlh
 DEV = "cuda:0"
-C, d, B = 100, 512, int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+d = int(sys.argv[4]) if len(sys.argv) > 4 else 512          # feature width (cfg1: 512, cfg5 ViT-L/14: 768)
+C = int(sys.argv[5]) if len(sys.argv) > 5 else 100
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 g = torch.Generator(device=DEV).manual_seed(0)
 x = torch.nn.functional.normalize(torch.randn(4096, d, generator=g, device=DEV), dim=1)
