@@ -133,7 +133,7 @@ def main():
     from engine.optimizer.optim import build_optimizer
     from engine.optimizer.scheduler import build_lr_scheduler
     from engine.tools.utils import set_random_seed
-    from finetune import _RowSource
+    from finetune import _RowSource, _draw_block
 
     repeats = args.repeats if args.repeats > 0 else max(3, min(50, -(-3000 // max(1, args.steps))))
 
@@ -219,15 +219,12 @@ def main():
             done = 0
             while done < n:
                 m = min(args.block, n - done)
-                bi, bt = [], []
-                for _ in range(m):
-                    bi.append(img_src.next_index())
-                    bt.append(txt_src.next_index())
+                bi, bt = _draw_block(img_src, txt_src, m)   # as finetune.train(): consecutive batches of an epoch as ONE index slice
                 engine.train_steps(tab_i, bi, tab_t, bt, scheduler.lr_table(m), first_step=optimizer.step_count + 1,
                                    alpha=1.0, scalars_out=slot(m))
                 optimizer.step_count += m
                 scheduler.step(scheduler.last_epoch + m)
-                rows += sum(int(b.numel()) for b in bi) + sum(int(b.numel()) for b in bt)
+                rows += sum(int(b[0].numel()) if isinstance(b, tuple) else int(b.numel()) for b in bi + bt)
                 done += m
             return rows
 
