@@ -15,6 +15,7 @@ is not on this path.
 from __future__ import annotations
 
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -484,18 +485,22 @@ def _eval_finish(stats_cpu, bs):
     return float((sums / counts).sum() / nb), float(st[:, 1].sum() / n)
 
 
-_PINNED = []        # ring of pinned host buffers for the evaluation read-backs (hipHostMalloc per call would cost more than the copy)
+_PINNED = threading.local()   # per thread (sweep_farm runs train() on worker threads): ring of pinned host buffers for the
+                              # evaluation read-backs (hipHostMalloc per call would cost more than the copy)
 
 
 def _pinned(n):
-    for k, buf in enumerate(_PINNED):
+    ring = getattr(_PINNED, "ring", None)
+    if ring is None:
+        ring = _PINNED.ring = []
+    for k, buf in enumerate(ring):
         if buf.numel() >= n:
-            _PINNED.append(_PINNED.pop(k))                 # least recently handed out first
-            return _PINNED[-1][:n]
-    if len(_PINNED) >= 4:
-        _PINNED.pop(0)
-    _PINNED.append(torch.empty(max(n, 1 << 16), dtype=torch.float32, pin_memory=True))
-    return _PINNED[-1][:n]
+            ring.append(ring.pop(k))                       # least recently handed out first
+            return ring[-1][:n]
+    if len(ring) >= 4:
+        ring.pop(0)
+    ring.append(torch.empty(max(n, 1 << 16), dtype=torch.float32, pin_memory=True))
+    return ring[-1][:n]
 
 
 def validate_many_begin(pairs, extra=None):
