@@ -22,6 +22,7 @@ both sides; `value` / `ms_per_step` are the MEDIAN block (all blocks are listed 
 fences and the launch ramp, which is why the median of many blocks is reported.
 """
 import argparse
+import contextlib
 import glob
 import json
 import os
@@ -143,7 +144,8 @@ def main():
     x_img, y_img = synth_rows(torch, n_img_local, D, C, 100 + rank, dev)
     x_txt, y_txt = synth_rows(torch, N_TXT, D, C, 7, dev)
     model = UMLClip(D, C, logit_scale_init=4.60517).to(dev)            # s = 100 (config/__init__.py:209-216)
-    model.zero_shot_init(FeatureTableAsText(x_txt, y_txt))
+    with contextlib.redirect_stdout(sys.stderr):            # (the mirror prints the reference's progress lines: stdout carries the JSON line only)
+        model.zero_shot_init(FeatureTableAsText(x_txt, y_txt))
     optimizer = build_optimizer(model.parameters(), "adamw", 1e-3, 0.01)
     scheduler = build_lr_scheduler(optimizer, "cosine", 50, 12800, warmup_type="linear", warmup_lr=1e-5)
     torch.manual_seed(1234 + rank)                                       # per-rank shuffles
