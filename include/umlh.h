@@ -187,9 +187,11 @@ int  umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_stre
                       float* scalars_out, void* stream);
 
 /* Batch <= 64 linear heads (the reference's own operating point: batch 8 / 32 / 64, 12 800 iterations,
- * engine/optimizer/default.py:3-45): umlh_train_steps runs all n_steps inside ONE persistent launch when the head is
- * fp32, has no img_proj, its width has a supported chunking (d in {16,32,48,64,80,96,128,256,384,512,640,768,1024}),
- * diagnostics are off and every step has at most 4 sample tiles (ceil(rows_img/16) + ceil(rows_txt/16) <= 4).  The
+ * engine/optimizer/default.py:3-45): umlh_train_steps runs all n_steps inside ONE persistent launch when the head has
+ * no img_proj, its width has a supported chunking (fp32: d in {16,32,48,64,80,96,128,256,384,512,640,768,1024}; bf16
+ * operand mode: the multiples of 128 among them), diagnostics are off and every step has at most 4 sample tiles
+ * (ceil(rows_img/16) + ceil(rows_txt/16) <= 4).  bf16 mode reads the fp32 tables and rounds operands at use (same
+ * values as the bf16 shadows of the three-kernel path); for d <= 640 the step's rows stay in LDS as bf16.  The
  * class axis is cut into 16-class slices, one workgroup per slice owns its part of W / m / v for the whole call; the
  * slices of a head exchange their softmax statistics once per step (in-launch, bounded waits).  UMLH_MICRO=0 in the
  * environment disables the path.  A wait that gives up (another process starving the device of CUs) is reported
