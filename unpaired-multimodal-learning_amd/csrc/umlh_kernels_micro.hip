@@ -165,10 +165,22 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
         *reinterpret_cast<f32x4m*>(Wl + r * LDW + 4 * q) = v;
     }
     // element (c, u, r) of this thread: class 4g + r, column c*CW + 64u + 16*wave + s16
-    float mreg[NCH][U][4], vreg[NCH][U][4];
+    // At 6 and 8 chunks (d = 768, 1024) the two moment arrays alone are 192 / 256 registers and the kernel spilled (d = 768 ran at
+    // 18.8 us per step against 11.9 at d = 640): the SECOND moment then stays in memory -- each step reads and writes the
+    // thread's 8 values of a chunk around that chunk's update (requested before the chunk's MFMA chains, L2-resident).
+    // At 8 chunks (d = 1024) the first moment follows it.
+    constexpr bool VMEM = NCH >= 6, MMEM = NCH >= 8;
+    float mreg[MMEM ? 1 : NCH][U][4], vreg[VMEM ? 1 : NCH][U][4];
+    float* vbase[4];                                        // VMEM: row pointers of this thread's 4 classes (clamped to valid rows)
+    float* mbase[4];
     const int colw = 16 * wave + s16;                       // column inside a 64-wide block
     const bool colok = colw < CW;                           // CW < 64: only the first CW columns exist
     const bool adam = H.opt_kind != UMLH_OPT_SGD;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        vbase[r] = H.v + (size_t)min(c0 + 4 * g + r, C - 1) * D + (colok ? colw : 0);
+        mbase[r] = H.m + (size_t)min(c0 + 4 * g + r, C - 1) * D + (colok ? colw : 0);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -177,8 +189,8 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             for (int r = 0; r < 4; ++r) {
                 const int cls = c0 + 4 * g + r, col = c * CW + 64 * u + colw;
                 const bool ok = cls < C && colok;
-                mreg[c][u][r] = ok ? H.m[(size_t)cls * D + col] : 0.f;
-                vreg[c][u][r] = (ok && adam) ? H.v[(size_t)cls * D + col] : 0.f;
+                if (!MMEM) mreg[c][u][r] = ok ? H.m[(size_t)cls * D + col] : 0.f;
+                if (!VMEM) vreg[c][u][r] = (ok && adam) ? H.v[(size_t)cls * D + col] : 0.f;
             }
     float scale[2] = {H.scales[0], H.scales[1]};
     float msc[2] = {0.f, 0.f}, vsc[2] = {0.f, 0.f};
@@ -571,12 +583,42 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
         // (Issuing the optimizer arithmetic of chunk c-1 between the MFMAs of chunk c was measured and bought nothing: the
         // f32-input MFMA runs at the f32 vector rate, the two compete for the same issue slots.)
         auto wptr = [&](int c) -> float* { return Wl + (4 * g) * LDW + c * CW + (colok ? colw : 0); };
-        auto upd_math = [&](auto kind, int c, const f32x4m (&dacc)[U], float (&pw)[U][4]) {
+        auto upd_math = [&](auto kind, int c, const f32x4m (&dacc)[U], float (&pw)[U][4], float (&vv)[U][4], float (&mv)[U][4]) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    opt_update_fast<decltype(kind)::value>(o, inv_bc2, dacc[u][r], pw[u][r], mreg[c][u][r], vreg[c][u][r]);
+                    opt_update_fast<decltype(kind)::value>(o, inv_bc2, dacc[u][r], pw[u][r], MMEM ? mv[u][r] : mreg[c][u][r],
+                                                           VMEM ? vv[u][r] : vreg[c][u][r]);
+        };
+        // VMEM: this thread's second moments of chunk c (class 4g + r, column c*CW + 64u + colw); rows >= C / missing columns
+        // read a valid element and are not written back
+        auto v_ptr = [&](int c, int u, int r) -> float* { return vbase[r] + (c * CW + 64 * u); };   // (constant offset: an immediate)
+        auto v_read = [&](int c, float (&vv)[U][4]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[u][r] = adam ? *v_ptr(c, u, r) : 0.f;
+        };
+        auto v_write = [&](int c, const float (&vv)[U][4]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (adam && c0 + 4 * g + r < C && colok) *v_ptr(c, u, r) = vv[u][r];
+        };
+        auto m_read = [&](int c, float (&mv)[U][4]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mv[u][r] = *(mbase[r] + (c * CW + 64 * u));
+        };
+        auto m_write = [&](int c, const float (&mv)[U][4]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + 4 * g + r < C && colok) *(mbase[r] + (c * CW + 64 * u)) = mv[u][r];
         };
         auto w_read = [&](int c, float (&pw)[U][4]) {
             const float* wp0 = wptr(c);
@@ -623,6 +665,9 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             }
             float pw[U][4];
             w_read(c, pw);
+            float vv[U][4], mv[U][4];
+            if (VMEM) v_read(c, vv);
+            if (MMEM) m_read(c, mv);
             __builtin_amdgcn_sched_barrier(0);              // reads stay ahead of the MFMA chains
             if (BF) {                                       // rows 16mm + 4e + g for element e of lane group g, in both operands
 #pragma unroll
@@ -649,8 +694,10 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             asm volatile("s_nop 7" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             MSTAMP(9);
-            upd_math(kind, c, dacc, pw);
+            upd_math(kind, c, dacc, pw, vv, mv);
             w_write(c, pw);
+            if (VMEM) v_write(c, vv);
+            if (MMEM) m_write(c, mv);
             MSTAMP(6);
             wg_barrier();                                   // chunk's buffer free; after the last chunk: the whole W slice updated
             MSTAMP(11);
@@ -696,8 +743,8 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
             for (int r = 0; r < 4; ++r) {
                 const int cls = c0 + 4 * g + r, col = c * CW + 64 * u + colw;
                 if (cls < C && colok) {
-                    H.m[(size_t)cls * D + col] = mreg[c][u][r];
-                    if (adam) H.v[(size_t)cls * D + col] = vreg[c][u][r];
+                    if (!MMEM) H.m[(size_t)cls * D + col] = mreg[c][u][r];
+                    if (adam && !VMEM) H.v[(size_t)cls * D + col] = vreg[c][u][r];
                 }
             }
     if (learn && slice == 0 && tid == 0) {
