@@ -42,12 +42,17 @@ def _rb(x, y, idx=None):
     return umlh.RowBatch(T(x, torch.float32), T(y, torch.int64), None if idx is None else T(idx, torch.int64))
 
 
+# stw 2: two sample tiles per wave of the 1-D forward; stw "q": the 2-D forward (128-row tiles x groups of 256 classes with
+# the cross-workgroup softmax merge) forced on at sizes far below the ones that select it by default
 @pytest.mark.parametrize("d,C,bi,bt,scale,stw", [(128, 10, 70, 33, 30.0, 1), (128, 100, 50, 64, 100.0, 1),
                                                  (512, 1000, 300, 257, 100.0, 1), (512, 1000, 300, 257, 100.0, 2), (1024, 1000, 70, 300, 100.0, 1),
-                                                 (384, 397, 40, 0, 50.0, 1), (256, 37, 0, 90, 20.0, 1)])
+                                                 (384, 397, 40, 0, 50.0, 1), (256, 37, 0, 90, 20.0, 1),
+                                                 (512, 1000, 300, 257, 100.0, "q"), (512, 1000, 0, 129, -100.0, "q"), (256, 600, 260, 200, 50.0, "q"),
+                                                 (512, 300, 130, 0, 100.0, "q"), (256, 1024, 128, 128, 30.0, "q")])
 def test_bf16_grad_step_vs_oracle_on_rounded_operands(d, C, bi, bt, scale, stw, monkeypatch):
     import umlh
-    monkeypatch.setenv("UMLH_BF16_STW", str(stw))
+    monkeypatch.setenv("UMLH_BF16_STW", "1" if stw == "q" else str(stw))
+    monkeypatch.setenv("UMLH_BF16_FWD2D", "1" if stw == "q" else "0")
     rng = np.random.default_rng(d + C)
     xi, yi, xt, yt, w = _case(rng, d, C, 400, 350, scale)
     ii = rng.permutation(400)[:bi] if bi else None

@@ -39,6 +39,7 @@ int umlh_launch_iota(long long* dst, long long n, hipStream_t stream);
 
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
+int umlh_bf16_launch_fwd_q(const FwdArgsB* a, int nq, int tiles, hipStream_t stream);
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream);
 int umlh_enc_launch_bias_act(float* y, const float* b, long long M, int N, int relu, hipStream_t st);
 int umlh_enc_launch_relu_bwd(const float* y, float* dy, long long n, hipStream_t st);
@@ -72,7 +73,8 @@ static int fail(int code, const char* fmt, ...) {
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 struct Layout {                 // workspace partition, in floats from the base
-    long long dzt, h, dht, slabs_head, slabs_proj, partials, diag_part, grads, w16, iota, zeros, dbg, wpt16, wht16, total;
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, diag_part, grads, w16, iota, zeros, dbg, wpt16, wht16, xch, total;
+    int fwd_nq;                 // bf16 2-D forward (fwd_ce_bf16_q): class groups per row tile, 0 = the 1-D kernel
     long long mc_flags, mc_xchg, mc_ext, mc_tab, mc_desc;   // micro-step region (umlh_kernels_micro.hip); mc_flags = 0: unsupported shape
     int mc_nwg, mc_nch, mc_cw;
     long long n_iota;
@@ -160,6 +162,18 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     const bool bfp = c.precision == UMLH_PREC_BF16 && c.has_proj;
     L.wpt16 = take(bfp ? (L.n_proj + 1) / 2 : 0);         // bf16 W_proj^T [d_img][d_shared]
     L.wht16 = take(bfp ? 1024LL * round_up(c.d_shared, 128) / 2 : 0);   // bf16 W_head^T by class chunks [16][d_shared^128][64]
+    // 2-D forward (128-row tiles x groups of 256 classes, cross-workgroup softmax merge; K resident in LDS): measured
+    // slower than the 1-D kernel at cfg2 (umlh_kernels_bf16.hip) -> opt-in, UMLH_BF16_FWD2D=1, whenever the shape allows.
+    L.fwd_nq = 0; L.xch = 0;
+    if (c.precision == UMLH_PREC_BF16 && c.num_classes > 256 && c.d_shared % 256 == 0 && c.d_shared <= 512) {
+        const char* e = getenv("UMLH_BF16_FWD2D");
+        const int mode = e ? atoi(e) : -1;
+        const int nq = (c.num_classes + 255) / 256;
+        if (mode == 1) {
+            L.fwd_nq = nq;
+            L.xch = take(2LL * (L.ldz / 128 + 2) * nq * 4 * 128);      // 8-byte granules
+        }
+    }
     // micro-step path: linear head whose width has a supported chunking (bf16 operand mode: widths that are multiples of 128)
     L.mc_flags = L.mc_xchg = L.mc_ext = L.mc_tab = L.mc_desc = 0;
     L.mc_nwg = (c.num_classes + UMLH_MICRO_CS - 1) / UMLH_MICRO_CS;
@@ -183,6 +197,7 @@ struct umlh_handle_s {
     bool bound;
     int ctw, wc, ts;            // fwd_ce tile configuration
     int stw;                    // bf16: 32-sample tiles per wave
+    unsigned fwd_epoch;         // bf16 2-D forward: launch tag of the exchange granules
     // state carried from umlh_grad_step to umlh_apply_update
     int last_rows_img, last_rows_txt;
     bool iota_ready;            // bf16: identity row-id table in the workspace initialised
@@ -290,7 +305,9 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
         int want = e ? atoi(e) : 1;
         if (h->wc == 8 && h->ctw >= 2 && want == 2) h->stw = 2;
         h->ts = umlh_bf16_fwd_ts(h->wc, h->stw);
+        if (L.fwd_nq) h->ts = 128;
     }
+    h->fwd_epoch = 0;
     h->last_rows_img = h->last_rows_txt = 0;
     h->global_rows_img = h->global_rows_txt = 0;
     h->profiling = false;
@@ -385,6 +402,12 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
         DeviceGuard dg_(h->device);
         const long long np = 4 * ((h->L.n_head + 1023) / 1024 + 2);
         if (hipMemset(ws(h, h->L.diag_part) + np, 0, 64 * sizeof(float)) != hipSuccess) return fail(UMLH_E_HIP, "umlh_bind: clearing the diagnostics ticket failed");
+    }
+    if (h->L.fwd_nq) {            // exchange granules of the 2-D forward: tag 0 = never written
+        DeviceGuard dg_(h->device);
+        if (hipMemset(ws(h, h->L.xch), 0, sizeof(float) * 2 * (size_t)(h->L.ldz / 128 + 2) * h->L.fwd_nq * 4 * 128) != hipSuccess)
+            return fail(UMLH_E_HIP, "umlh_bind: clearing the forward exchange region failed");
+        h->fwd_epoch = 0;
     }
     if (h->L.mc_flags) {          // epoch flags, status word and exchange records start from zero (bind time only)
         DeviceGuard dg_(h->device);
@@ -896,7 +919,15 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         fb.dbg = h->dbg_fwd;
         fb.learn = c.learnable_temp;
         fb.row_stats = h->row_stats;
-        fb.stamps = fb.dbg == 9 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
+        fb.stamps = (fb.dbg == 9 || fb.dbg >= 20) ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
+        if (L.fwd_nq) {
+            fb.xch = reinterpret_cast<unsigned long long*>(ws(h, L.xch));
+            if (++h->fwd_epoch == 0) h->fwd_epoch = 1;
+            fb.epoch = h->fwd_epoch;
+            fb.wtiles = cpad / 32;
+            fb.ntiles = nb0 + nb1;
+            HIPCHK(umlh_bf16_launch_fwd_q(&fb, L.fwd_nq, nb0 + nb1, st), "fwd_ce_bf16_q");
+        } else
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
         mark(h, 2, st);
         *n_slabs_head = 0; *n_slabs_proj = 0;

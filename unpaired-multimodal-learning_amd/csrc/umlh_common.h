@@ -121,6 +121,10 @@ struct FwdArgsB {
     int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
     unsigned long long* stamps;  // diagnostic build only (UMLH_DBG_FWD=9): [grid][8] s_memtime stamps of wave 0
     float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
+    unsigned long long* xch;     // fwd_ce_bf16_q: [blocks][4 fields][128 rows] epoch-tagged exchange granules
+    unsigned epoch;              // fwd_ce_bf16_q: tag of this launch (never 0)
+    int   ntiles;                // fwd_ce_bf16_q: row tiles of this launch (the grid is rounded up to 8 of them)
+    int   wtiles;                // fwd_ce_bf16_q: 32-class tiles per k-step of the W shadow (cpad / 32)
 };
 
 // bf16 GEMM out[m][n] = sum_k A[m][k] * B[k][n] (kernel dw_bf16<AM, OM>).  Written for dW = dZ^T F; the 2-layer

@@ -520,6 +520,346 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
 }
 
 // --------------------------------------------------------------------------- //
+// fused forward + cross entropy, bf16 operands, 2-D decomposition (class groups x row tiles)
+// --------------------------------------------------------------------------- //
+// fwd_ce_bf16 gives every workgroup 32 sample rows and ALL classes, so each CU streams the whole W shadow
+// (1 MB at cfg2) from L2 at the ~46 B/clk one CU sustains: 25k of its 35k cycles.  Here a workgroup owns 128
+// sample rows (resident in LDS for the whole K) and a GROUP of 256 classes (one 32-class tile per wave, streamed
+// through a 16-deep register ring): 128 KB of X + 256 KB of W per CU = 0.37x the stream for the same MFMA work.
+// The NQ workgroups of a row tile (adjacent block ids = consecutive dispatch slots) exchange their per-row
+// (max, sum of exp, sum of exp*raw, label logit) through 8-byte epoch-tagged granules in global memory -- the
+// online-softmax merge of fwd_ce_bf16's wave records, one level up -- and then write their own slice of dZ^T.
+// Spins are bounded; a timed-out exchange poisons the step's loss with NaN instead of hanging.
+// MEASURED (cfg2, cycle stamps scripts/fwd_stamps.py): correct, but not faster than fwd_ce_bf16 -- 24.7 vs 21.8 us by the
+// raw event interval.  The main loop shrinks as designed (25k -> 12k cycles) yet the workgroup lives 37k cycles against 34.6k:
+// ~9k before the first MFMA (row-id round trip, then the gather from HBM), and an epilogue of 16k (6.2k records + 6k merge
+// through device-coherent memory + 3.7k dZ) that the 1-D kernel half hides behind the stream of its slower wave per SIMD
+// (its two waves end the stream 8k cycles apart; here four barriers keep all eight in step).  Neither removing the W refills nor
+// the B reads (analysis build, dbg 21 / 22) moves the loop by more than 2k cycles.  Opt-in only: UMLH_BF16_FWD2D=1.
+__device__ __forceinline__ void fq_store_granule(unsigned long long* p, unsigned epoch, float v) {
+    __hip_atomic_store(p, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int FQ_TS = 128;                       // sample rows per workgroup
+constexpr int FQ_XRS = 520;                      // LDS row stride (shorts): 1040 B = odd multiple of 16 B
+constexpr int FQ_XT_BYTES = FQ_TS * FQ_XRS * 2;
+constexpr int FQ_SMEM = FQ_XT_BYTES + sizeof(float) * (4 * 4 * 8 * 32 + 4 * 128 + 16);
+
+template <int NQ, int NKS>
+__global__ __launch_bounds__(512) void fwd_ce_bf16_q(FwdArgsB a) {
+    constexpr int STW = 4, XRS = FQ_XRS, PD = 16, ZRS = 20, NG = NKS / PD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Xt = reinterpret_cast<u16*>(smem_raw);                          // [128][XRS]: the tile's rows, whole K
+    unsigned* dzstage = reinterpret_cast<unsigned*>(smem_raw);           // aliases Xt after the main loop
+    float* rec = reinterpret_cast<float*>(smem_raw + FQ_XT_BYTES);       // [st][field][wave][32]
+    float* fin = rec + 4 * 4 * 8 * 32;                                   // [field][128]: max, coef / S, coef
+    float* red2 = fin + 4 * 128;                                         // [2][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    // XCD-aware decode: workgroups b and b + 8 share an XCD (round-robin dispatch).  The NQ class groups of a row tile take
+    // CONSECUTIVE slots of ONE XCD: the tile's gathered rows come from HBM once (the partners hit them in their L2), the
+    // exchange stays inside that L2's neighbourhood, and partners are dispatched back to back (the oldest unfinished row tile
+    // of an XCD is always fully resident, so the bounded spins below cannot wait on an undispatched partner).
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int q = slot % NQ, rtile = (slot / NQ) * 8 + xcd;
+    if (rtile >= a.ntiles) return;                                      // grid is rounded up to 8 tiles (whole partner sets leave)
+    const int sidx = rtile >= a.seg[1].blk0 ? 1 : 0;
+    const SegDescB& sg = a.seg[sidx];
+#define QSTAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)(rtile * NQ + q) * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    QSTAMP(0);
+    const int row0 = (rtile - sg.blk0) * FQ_TS;
+    const int C = a.C;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wave_c0 = (q * 8 + wave_u) * 32;                          // first class of this wave's tile (a tile past C
+                                                                         // multiplies the shadow's zero padding and is masked)
+    // X pieces: K block kb (128 wide) = 2048 pieces of 16 B; piece tid + 512 j -> row (tid >> 4) + 32 j, column tid & 15
+    const u16* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = min(row0 + (tid >> 4) + 32 * j, sg.rows - 1);
+        int64_t rid = sg.feat_index ? sg.feat_index[r] : (int64_t)r;
+        xsrc[j] = sg.feats + (size_t)rid * sg.ld + 8 * (tid & 15);
+    }
+    int labs[STW];
+#pragma unroll
+    for (int st = 0; st < STW; ++st) {
+        int r = min(row0 + st * 32 + l31, sg.rows - 1);
+        labs[st] = (int)sg.labels[sg.label_index ? sg.label_index[r] : (int64_t)r];
+    }
+    f32x16 acc[STW];
+#pragma unroll
+    for (int st = 0; st < STW; ++st)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[st][i] = 0.f;
+
+    // fragment (k-step ks, class tile t) = 1 KiB at W + ((ks * wtiles + t) * 64 + lane) * 8
+    const u16* wlane = a.W + ((size_t)(q * 8 + wave_u) * 64 + lane) * 8;
+    const size_t wstep = (size_t)a.wtiles * 512;
+    bf16x8 ring[PD];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) ring[d] = *reinterpret_cast<const bf16x8*>(wlane + d * wstep);
+    u32x4 xr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xr[j] = *reinterpret_cast<const u32x4*>(xsrc[j]);
+    QSTAMP(1);
+    const u16* xrow = Xt + l31 * XRS + h * 8;
+    // Straight-line main loop (NKS is a template parameter: a runtime group loop made hipcc shuffle the ring between
+    // its peeled variants and spill).  Per 128-wide K block: publish the block (its rows were loaded one block ago), start
+    // the loads of the next one, ONE barrier (the tile is never overwritten), then 8 k-steps of {4 B reads, 4 MFMAs, refill}.
+    // B fragments are read one k-step ahead of their MFMAs (two register sets)
+    bf16x8 b[2][STW];
+#pragma unroll
+    for (int kb = 0; kb < 2 * NG; ++kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<u32x4*>(Xt + ((tid >> 4) + 32 * j) * XRS + kb * 128 + 8 * (tid & 15)) = xr[j];
+        if (kb + 1 < 2 * NG) {                          // (requesting every block up front instead measured slower: 21.6k vs 20.5k cycles)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[j] = *reinterpret_cast<const u32x4*>(xsrc[j] + (kb + 1) * 128);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < STW; ++st) b[0][st] = *reinterpret_cast<const bf16x8*>(xrow + st * 32 * XRS + kb * 128);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const int ks = kb * 8 + d, slot = ks % PD, cur = d & 1;
+            if (d + 1 < 8) {
+#pragma unroll
+                for (int st = 0; st < STW; ++st) b[cur ^ 1][st] = UMLH_ABL(a.dbg == 22) ? b[cur][st] : *reinterpret_cast<const bf16x8*>(xrow + st * 32 * XRS + (ks + 1) * 16);
+            }
+#pragma unroll
+            for (int st = 0; st < STW; ++st)
+                acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot], b[cur][st], acc[st], 0, 0, 0);
+            if (ks + PD < NKS && !UMLH_ABL(a.dbg == 21)) ring[slot] = *reinterpret_cast<const bf16x8*>(wlane + (ks + PD) * wstep);
+            if (d + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, STW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, STW, 0);
+            if (ks + PD < NKS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    }
+    QSTAMP(2);
+
+    // ---------------- epilogue, phase A: wave-local records of the 4 sample tiles ----------------
+    const float scale = *sg.scale_ptr;
+    const float sgn = scale < 0.f ? -1.f : 1.f;
+    const float LOG2E = 1.4426950408889634f;
+    const float ascale = __builtin_fabsf(scale);
+    const float asl2 = __builtin_fmaxf(ascale * LOG2E, 1e-20f);
+    const float MASKED = -1e30f;
+    const bool learn = a.learn != 0;
+    if (scale < 0.f) {
+#pragma unroll
+        for (int st = 0; st < STW; ++st)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[st][i] = -acc[st][i];
+    }
+    if (wave_c0 + 32 > C) {                              // wave-uniform: the tile that straddles C, and all-padding tiles
+#pragma unroll
+        for (int st = 0; st < STW; ++st)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[st][i] = wave_c0 + acc_row(i, h) < C ? acc[st][i] : MASKED;
+    }
+    float mown[STW], rawy_w[STW];
+#pragma unroll
+    for (int st = 0; st < STW; ++st) {
+        const bool valid = row0 + st * 32 + l31 < sg.rows;
+        const int lab = valid ? labs[st] : -1;
+        float mk = acc[st][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mk = __builtin_fmaxf(mk, acc[st][i]);
+        mk = __builtin_fmaxf(mk, __shfl_xor(mk, 32));
+        const int rel = lab - wave_c0;
+        const bool mine = rel >= 0 && rel < 32 && ((rel >> 2) & 1) == h;
+        float rawy;
+        {
+            const int reg = (rel & 3) | ((rel >> 3) & 3) << 2;
+            float t[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = acc[st][i];
+#pragma unroll
+            for (int bit = 0, n = 16; n > 1; ++bit, n >>= 1) {
+                const bool up = (reg >> bit) & 1;
+#pragma unroll
+                for (int j = 0; j < n / 2; ++j) t[j] = up ? t[2 * j + 1] : t[2 * j];
+            }
+            rawy = mine ? t[0] : 0.f;
+        }
+        rawy += __shfl_xor(rawy, 32);
+        const float mwl = wave_c0 >= C ? 0.f : mk * asl2;
+        int first = 16;
+        f32x2v se2 = {0.f, 0.f}, serw2 = {0.f, 0.f};
+        const f32x2v sl2v = {asl2, asl2}, nmwl = {-mwl, -mwl};
+#pragma unroll
+        for (int i = 14; i >= 0; i -= 2) {
+            const f32x2v raw = {acc[st][i], acc[st][i + 1]};
+            first = raw[1] == mk ? i + 1 : first;
+            first = raw[0] == mk ? i : first;
+            const f32x2v t = __builtin_elementwise_fma(raw, sl2v, nmwl);
+            const f32x2v e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            se2 += e;
+            serw2 = __builtin_elementwise_fma(e, raw, serw2);
+            acc[st][i] = e[0];
+            acc[st][i + 1] = e[1];
+        }
+        int mi = first < 16 ? wave_c0 + (first & 3) + 8 * ((first >> 2) & 3) + 4 * h : 0x7fffffff;
+        mi = min(mi, __shfl_xor(mi, 32));
+        float se = se2[0] + se2[1], serw = serw2[0] + serw2[1];
+        se += __shfl_xor(se, 32);
+        serw += __shfl_xor(serw, 32);
+        const bool hit = mi == lab;
+        if (h == 0) {
+            float* rb = rec + (st * 4 * 8 + wave) * 32 + l31;
+            rb[0 * 8 * 32] = mk;
+            rb[1 * 8 * 32] = hit ? -se : se;
+            rb[2 * 8 * 32] = serw;
+            rb[3 * 8 * 32] = rawy;
+        }
+        mown[st] = mk;
+        rawy_w[st] = rawy;
+    }
+    __syncthreads();
+    QSTAMP(3);
+    // ---------------- phase B: thread t < 128 merges row t over the 8 waves, then over the NQ class groups ----------------
+    float bl = 0.f, bc = 0.f, bg = 0.f;
+    if (tid < 128) {
+        const float* rb = rec + ((tid >> 5) * 4 * 8) * 32 + (tid & 31);
+        float mk = rb[0], win = rb[8 * 32];
+        float om[8], os[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { om[w] = rb[w * 32]; os[w] = rb[(8 + w) * 32]; }
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { win = om[w] > mk ? os[w] : win; mk = __builtin_fmaxf(mk, om[w]); }
+        float se = 0.f, serw = 0.f, rawy = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float fw = __builtin_amdgcn_exp2f((om[w] - mk) * asl2);
+            se = __builtin_fmaf(__builtin_fabsf(os[w]), fw, se);
+            serw = __builtin_fmaf(rb[(16 + w) * 32], fw, serw);
+            rawy += rb[(24 + w) * 32];
+        }
+        bool hit = win < 0.f;
+        bool bad = false;
+        if (NQ > 1) {
+            unsigned long long* mine_rec = a.xch + ((size_t)(rtile * NQ + q) * 4) * 128 + tid;
+            fq_store_granule(mine_rec, a.epoch, mk);
+            fq_store_granule(mine_rec + 128, a.epoch, hit ? -se : se);
+            fq_store_granule(mine_rec + 256, a.epoch, serw);
+            fq_store_granule(mine_rec + 384, a.epoch, rawy);
+            float gm[NQ], gs[NQ], gw[NQ], gy[NQ];
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+            for (int p = 0; p < NQ; ++p) {
+                if (p == q) { gm[p] = mk; gs[p] = hit ? -se : se; gw[p] = serw; gy[p] = rawy; continue; }
+                const unsigned long long* pr = a.xch + ((size_t)(rtile * NQ + p) * 4) * 128 + tid;
+                unsigned long long g4[4];
+                for (unsigned spin = 0; !bad; ++spin) {
+                    bool ok = true;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        g4[f] = __hip_atomic_load(pr + f * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (unsigned)(g4[f] >> 32) == a.epoch;
+                    }
+                    if (__all(ok)) break;
+                    if ((spin & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) bad = true;   // 2 s at 100 MHz
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                gm[p] = __uint_as_float((unsigned)g4[0]); gs[p] = __uint_as_float((unsigned)g4[1]);
+                gw[p] = __uint_as_float((unsigned)g4[2]); gy[p] = __uint_as_float((unsigned)g4[3]);
+            }
+            mk = gm[0]; win = gs[0];
+#pragma unroll
+            for (int p = 1; p < NQ; ++p) { win = gm[p] > mk ? gs[p] : win; mk = __builtin_fmaxf(mk, gm[p]); }
+            hit = win < 0.f;
+            se = 0.f; serw = 0.f; rawy = 0.f;
+#pragma unroll
+            for (int p = 0; p < NQ; ++p) {
+                const float fw = __builtin_amdgcn_exp2f((gm[p] - mk) * asl2);
+                se = __builtin_fmaf(__builtin_fabsf(gs[p]), fw, se);
+                serw = __builtin_fmaf(gw[p], fw, serw);
+                rawy += gy[p];
+            }
+        }
+        const int r = row0 + tid;
+        const bool valid = r < sg.rows;
+        const float coef = valid ? sg.w_over_rows * scale : 0.f;
+        fin[tid] = mk;
+        fin[128 + tid] = coef * __builtin_amdgcn_rcpf(se);
+        fin[256 + tid] = coef;
+        if (q == 0 && valid) {
+            const float ce = __logf(se) + mk * ascale - rawy * ascale;
+            bl = bad ? __builtin_nanf("") : ce;
+            bc = hit ? 1.f : 0.f;
+            bg = learn ? sgn * (serw / se - rawy) : 0.f;
+            if (a.row_stats != nullptr) {
+                float* rs = a.row_stats + 2 * ((size_t)(sidx ? a.seg[0].rows : 0) + r);
+                rs[0] = ce;
+                rs[1] = hit ? 1.f : 0.f;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            bl += __shfl_xor(bl, off);
+            bc += __shfl_xor(bc, off);
+            bg += __shfl_xor(bg, off);
+        }
+        if (lane == 0) { red2[wave * 4 + 0] = bl; red2[wave * 4 + 1] = bc; red2[wave * 4 + 2] = bg; }
+    }
+    __syncthreads();
+    QSTAMP(4);
+    if (q == 0 && tid == 0) {
+        float* o = a.partials + (size_t)rtile * 4;
+        o[0] = red2[0] + red2[4]; o[1] = red2[1] + red2[5]; o[2] = red2[2] + red2[6]; o[3] = 0.f;
+    }
+    // ---------------- phase C: this wave's 32 class rows of dZ^T, tile by tile ----------------
+    if (a.dzt != nullptr) {
+        unsigned* dzs = dzstage + wave * (32 * ZRS);                      // [32 class rows][ZRS dwords]
+        u16* dzs16 = reinterpret_cast<u16*>(dzs);
+        const bool odd = lane & 1;
+        const unsigned psel = odd ? 0x03020706u : 0x05040100u;
+        unsigned* dzl = dzs + (4 * h + (odd ? 1 : 0)) * ZRS + (l31 >> 1);
+#pragma unroll
+        for (int st = 0; st < STW; ++st) {
+            const int smp = st * 32 + l31;
+            const float mg = fin[smp], icb = fin[128 + smp], coef = fin[256 + smp];
+            const float fown = __builtin_amdgcn_exp2f((mown[st] - mg) * asl2);
+            const float ic = icb * fown;
+            const f32x2v icv = {ic, ic};
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2v m = f32x2v{acc[st][i], acc[st][i + 1]} * icv;
+                const unsigned own = __builtin_bit_cast(unsigned, __builtin_convertvector(m, bf16x2v));
+                const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true);
+                dzl[((i & 3) + 8 * (i >> 2)) * ZRS] = __builtin_amdgcn_perm(nbr, own, psel);
+            }
+            const int lab = row0 + smp < sg.rows ? labs[st] : -1;
+            const int rel = lab - wave_c0;
+            if (h == 0 && rel >= 0 && rel < 32) {
+                const float mwl = mown[st] * asl2;                        // a tile that holds a label is never all padding
+                const float ey = __builtin_amdgcn_exp2f(__builtin_fmaf(rawy_w[st], asl2, -mwl));
+                const f32x2v v = {__builtin_fmaf(ey, ic, -coef), 0.f};
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+                dzs16[rel * (2 * ZRS) + l31] = (u16)(pk & 0xffffu);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int colbase = sg.col0 + row0 + st * 32;
+            u16* gbase = a.dzt + ((size_t)(colbase >> 6) * a.crows) * 64 + (colbase & 63);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int lr = it * 16 + (lane >> 2);
+                const int cls = wave_c0 + lr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(dzs + lr * ZRS + (lane & 3) * 4);
+                if (cls < C) *reinterpret_cast<u32x4*>(gbase + (size_t)cls * 64 + (lane & 3) * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    QSTAMP(5);
+#undef QSTAMP
+}
+
+// --------------------------------------------------------------------------- //
 // dW[m][n] = sum_r dZ^T[m][r] * F[r][n]   (bf16 operands, fp32 split-K slabs)
 // 128x128 tile, 4 waves (2x2) of 64x64.  A rows are k-contiguous (ds_read_b128);
 // the feature rows F are k-major in memory, so the B fragment (8 consecutive k for one
@@ -807,6 +1147,29 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
         hipLaunchKernelGGL((fwd_ce_bf16<CT, W, S>), dim3(grid), dim3(512), sm, stream, *a);          \
         return (int)hipGetLastError();                                                               \
     }
+
+// 2-D forward: grid = row tiles (128 rows; seg[].blk0 in tile units) x nq class groups of 256
+#define FWDQ_CASE(NQ_, NKS_)                                                                                       \
+    if (nq == NQ_ && a->K == 16 * NKS_) {                                                                          \
+        static unsigned long long attr_done = 0;                                                                   \
+        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_bf16_q<NQ_, NKS_>),           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, FQ_SMEM);               \
+            if (e != hipSuccess) return (int)e;                                                                    \
+            attr_done |= 1ULL << (dev_ & 63);                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL((fwd_ce_bf16_q<NQ_, NKS_>), dim3((tiles + 7) / 8 * 8 * NQ_), dim3(512), FQ_SMEM, stream, *a);        \
+        return (int)hipGetLastError();                                                                             \
+    }
+
+int umlh_bf16_launch_fwd_q(const FwdArgsB* a, int nq, int tiles, hipStream_t stream) {
+    if (tiles <= 0) return 0;
+    if (!a->xch || a->epoch == 0 || a->C > 256 * nq || a->wtiles < 8 * nq || a->ntiles != tiles) return (int)hipErrorInvalidValue;
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    FWDQ_CASE(2, 32) FWDQ_CASE(3, 32) FWDQ_CASE(4, 32) FWDQ_CASE(2, 16) FWDQ_CASE(3, 16) FWDQ_CASE(4, 16)
+    return (int)hipErrorInvalidValue;
+}
 
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream) {
     if (grid <= 0) return 0;
