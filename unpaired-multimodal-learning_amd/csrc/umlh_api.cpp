@@ -441,6 +441,7 @@ static int check_batch(umlh_handle_t h, const umlh_batch_t* b, int cap, const ch
 static OptArgs make_opt(const umlh_config_t& c, const umlh_hyper_t& hy) {
     OptArgs o;
     memset(&o, 0, sizeof(o));
+    o.plain = umlh_plain_stores();
     o.kind = c.optimizer;
     o.lr = (float)hy.lr;
     o.decay = (float)(1.0 - hy.lr * c.weight_decay);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "umlh.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -14,6 +15,28 @@ constexpr int KT = 16;
 
 // Row of a 32x32 MFMA accumulator register: C/D layout is
 // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// Write-through (sc1) stores for everything a kernel hands to the NEXT launch (dZ^T, split-K slabs): the bytes leave for
+// memory when the instruction retires instead of sitting dirty in the XCD's L2 until the end-of-kernel write-back that the
+// dependent launch waits for (microarch guide, rows 'boundary' and 'publish-large').  cfg2 bf16 step 46.7 -> 44.8 us.
+// UMLH_WT=0 in the environment selects plain stores (args.plain = 1) for A/B timing.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void store_wt_f32(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_out_f32x4(float* p, f32x4v v, int plain) {
+    if (plain) *reinterpret_cast<f32x4v*>(p) = v;
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_out_f32(float* p, float v, int plain) {
+    if (plain) *p = v; else store_wt_f32(p, v);
+}
+#endif
+static inline int umlh_plain_stores() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UMLH_WT"); v = (e && e[0] == '0') ? 1 : 0; }
+    return v;
+}
+
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 // ---- one modality's rows as the forward kernel sees them ----
@@ -37,6 +60,7 @@ struct FwdArgs {
     float* dzt;                  // [C, ldz] dZ^T (class-major), NULL = eval (no gradient)
     int   ldz;
     float* partials;             // [grid][4] = {loss_sum, correct, gscale_sum, 0}
+    int   plain;                 // 1 = plain stores for dZ^T (default 0: write-through, see store_wt_f32)
     float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
 };
 
@@ -76,6 +100,7 @@ __device__ __forceinline__ float epilogue_apply(const Epilogue& e, float v, long
 // ---- generic fp32 GEMM: out[m][n] = alpha * sum_k A(m,k) * B(n,k) ----
 struct GemmArgs {
     const float* A;  const float* B;  float* out;
+    int   plain;                 // 1 = plain output stores (default 0: write-through, see store_wt_f32)
     const int64_t* a_rows;       // TA==0: gather of A rows by m (NULL = identity)
     const int64_t* k_rows;       // TB==1: gather of B rows by k (NULL = identity)
     int   M, N, K;
@@ -117,6 +142,7 @@ struct FwdArgsB {
     u16*  dzt;                   // bf16 dZ^T, column-chunk-major [cols/64][crows][64]; NULL = eval
     int   crows;                 // class rows per column chunk (C rounded up to 128)
     float* partials;
+    int   plain;                 // 1 = plain dZ^T stores (default 0: write-through)
     int   dbg;                   // 9 = cycle stamps; other values: timing-only ablations (analysis build -DUMLH_ABLATIONS only)
     int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale)
     unsigned long long* stamps;  // diagnostic build only (UMLH_DBG_FWD=9): [grid][8] s_memtime stamps of wave 0
@@ -137,6 +163,7 @@ struct DwArgsB {
     const u16* B2; const int64_t* k_rows2; int ldb2;    // text-side feature rows (k >= k_switch)
     float* out;                  // fp32 slabs [splits][M][ldo]
     const u16* zeros;            // >= 16 B of zeros (source of masked loads)
+    int   plain;                 // 1 = plain slab stores (default 0: write-through)
     int   dbg;                   // timing-only ablations, analysis build -DUMLH_ABLATIONS only: bit0 = no A traffic, bit1 = no F traffic, bit2 = no main loop
     int   M, N, K, lda, ldo, k_chunk, k_switch, k_valid1, k_valid2, nsplit;
     int   nsplit1;               // slabs [0, nsplit1) cover k in [0, k_switch), the rest [k_switch, K): k_chunk rows each
@@ -162,6 +189,7 @@ struct OptArgs {
     float neg_step_size;         // -(lr / (1 - beta1^t))
     float bc2_sqrt;              // sqrt(1 - beta2^t)
     float beta1, one_m_beta1, beta2, one_m_beta2, eps, momentum, wd;
+    int   plain;                 // 1 = plain stores of the updated state (default 0: write-through, see store_wt_f32)
 };
 
 struct FinalizeArgs {

@@ -31,6 +31,12 @@ constexpr int KTB = 32;     // bf16 k elements staged per LDS chunk (two MFMA k-
 constexpr int RSB = 40;     // LDS row stride in shorts for k-contiguous tiles: 64 B data + 16 B pad
                             // -> ds_read_b128 of 16 different rows hits 16 different 16-B bank groups
 
+// write-through (sc1) stores: the data is on its way to memory when the instruction retires instead of sitting dirty in
+// the XCD's L2 until the end-of-kernel write-back that the next (dependent) launch has to wait for
+__device__ __forceinline__ void store_wt_b128(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ u16 f2bf(float f) {
     __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32, round-to-nearest-even
     return __builtin_bit_cast(u16, b);
@@ -483,7 +489,10 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
                 const int lr = it * 16 + (lane >> 2);                           // row within the wave's class range
                 const int cls = wave_c0 + lr;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(dzs + lr * ZRS + (lane & 3) * 4);
-                if (cls < C) *reinterpret_cast<u32x4*>(gbase + (size_t)cls * 64 + (lane & 3) * 8) = v;
+                if (cls < C) {
+                    if (!a.plain) store_wt_b128(gbase + (size_t)cls * 64 + (lane & 3) * 8, v);
+                    else *reinterpret_cast<u32x4*>(gbase + (size_t)cls * 64 + (lane & 3) * 8) = v;
+                }
             }
             if (STW > 1) __builtin_amdgcn_wave_barrier();                      // next tile reuses the staging slice
         }
@@ -850,7 +859,10 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16_q(FwdArgsB a) {
                 const int lr = it * 16 + (lane >> 2);
                 const int cls = wave_c0 + lr;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(dzs + lr * ZRS + (lane & 3) * 4);
-                if (cls < C) *reinterpret_cast<u32x4*>(gbase + (size_t)cls * 64 + (lane & 3) * 8) = v;
+                if (cls < C) {
+                    if (!a.plain) store_wt_b128(gbase + (size_t)cls * 64 + (lane & 3) * 8, v);
+                    else *reinterpret_cast<u32x4*>(gbase + (size_t)cls * 64 + (lane & 3) * 8) = v;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1087,7 +1099,7 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
             for (int e = 0; e < 16; ++e) {
                 int m = m0 + wm * 64 + i * 32 + acc_row(e, h);
                 if (m >= g.M) continue;
-                if (OM == 0) out[(size_t)m * g.ldo + n] = acc[i][e];
+                if (OM == 0) store_out_f32(out + (size_t)m * g.ldo + n, acc[i][e], g.plain);
                 else {
                     const u16 v = f2bf(acc[i][e]);
                     if (OM == 1) o16[(size_t)m * g.ldo + n] = v;
@@ -1144,7 +1156,8 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
             if (e != hipSuccess) return (int)e;                                                      \
             attr_done |= 1ULL << (dev_ & 63);                                                        \
         }                                                                                            \
-        hipLaunchKernelGGL((fwd_ce_bf16<CT, W, S>), dim3(grid), dim3(512), sm, stream, *a);          \
+        FwdArgsB c_ = *a; c_.plain = umlh_plain_stores();                                            \
+        hipLaunchKernelGGL((fwd_ce_bf16<CT, W, S>), dim3(grid), dim3(512), sm, stream, c_);          \
         return (int)hipGetLastError();                                                               \
     }
 
@@ -1158,7 +1171,8 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
             if (e != hipSuccess) return (int)e;                                                                    \
             attr_done |= 1ULL << (dev_ & 63);                                                                      \
         }                                                                                                          \
-        hipLaunchKernelGGL((fwd_ce_bf16_q<NQ_, NKS_>), dim3((tiles + 7) / 8 * 8 * NQ_), dim3(512), FQ_SMEM, stream, *a);        \
+        FwdArgsB c_ = *a; c_.plain = umlh_plain_stores();                                                          \
+        hipLaunchKernelGGL((fwd_ce_bf16_q<NQ_, NKS_>), dim3((tiles + 7) / 8 * 8 * NQ_), dim3(512), FQ_SMEM, stream, c_);        \
         return (int)hipGetLastError();                                                                             \
     }
 
@@ -1194,9 +1208,11 @@ int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_
     if (g->k_switch % DKT != 0 || g->bcs < 64 || g->N % 8 != 0) return (int)hipErrorInvalidValue;
     if ((am == 1 && !g->a_rows) || (om != 0 && (!g->out16 || splits != 1))) return (int)hipErrorInvalidValue;
     dim3 grid(((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits);
-    if (am == 0 && om == 0) hipLaunchKernelGGL((dw_bf16<0, 0>), grid, dim3(512), 0, stream, *g);
-    else if (am == 1 && om == 1) hipLaunchKernelGGL((dw_bf16<1, 1>), grid, dim3(512), 0, stream, *g);
-    else if (am == 0 && om == 2) hipLaunchKernelGGL((dw_bf16<0, 2>), grid, dim3(512), 0, stream, *g);
+    DwArgsB c = *g;
+    c.plain = umlh_plain_stores();
+    if (am == 0 && om == 0) hipLaunchKernelGGL((dw_bf16<0, 0>), grid, dim3(512), 0, stream, c);
+    else if (am == 1 && om == 1) hipLaunchKernelGGL((dw_bf16<1, 1>), grid, dim3(512), 0, stream, c);
+    else if (am == 0 && om == 2) hipLaunchKernelGGL((dw_bf16<0, 2>), grid, dim3(512), 0, stream, c);
     else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
                 int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
                 if (cls < C) {
                     float p = acc[ct][i] * inv;
-                    dst[(size_t)cls * a.ldz] = (p - (cls == lab ? 1.f : 0.f)) * coef;
+                    store_out_f32(dst + (size_t)cls * a.ldz, (p - (cls == lab ? 1.f : 0.f)) * coef, a.plain);
                 }
             }
     }
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
                 if (m < g.M) {
                     float v = acc[i][j][e] * alpha;
                     if (g.epi.on && gridDim.z == 1) v = epilogue_apply(g.epi, v, (long long)m * g.ldo + n, n);   // dense result: ldo == N
-                    out[(size_t)m * g.ldo + n] = v;
+                    store_out_f32(out + (size_t)m * g.ldo + n, v, g.plain);
                 }
             }
         }
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void dw_f32(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 64 + i * 32 + acc_row(e, h);
-                if (m < g.M) out[(size_t)m * g.ldo + n] = acc[i][j][e] * alpha;
+                if (m < g.M) store_out_f32(out + (size_t)m * g.ldo + n, acc[i][j][e] * alpha, g.plain);
             }
         }
 }
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void reduce_update(const float* __restrict__ s
         f32x4v gsum = {0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < n_slabs; ++s)
             gsum += *reinterpret_cast<const f32x4v*>(slabs + (size_t)s * slab_stride + i);
-        if (grad_out) *reinterpret_cast<f32x4v*>(grad_out + i) = gsum;
+        if (grad_out) store_out_f32x4(grad_out + i, gsum, o.plain);
         if (MODE == 1) {
             f32x4v pp = *reinterpret_cast<f32x4v*>(p + i);
             f32x4v mm = *reinterpret_cast<f32x4v*>(m + i);
@@ -885,9 +885,9 @@ __global__ __launch_bounds__(256) void reduce_update(const float* __restrict__ s
                 opt_update(o, gsum[j], a, b, c);
                 pp[j] = a; mm[j] = b; vv[j] = c;
             }
-            *reinterpret_cast<f32x4v*>(p + i) = pp;
-            *reinterpret_cast<f32x4v*>(m + i) = mm;
-            if (o.kind != UMLH_OPT_SGD) *reinterpret_cast<f32x4v*>(v + i) = vv;
+            store_out_f32x4(p + i, pp, o.plain);
+            store_out_f32x4(m + i, mm, o.plain);
+            if (o.kind != UMLH_OPT_SGD) store_out_f32x4(v + i, vv, o.plain);
         }
     } else {
         for (long long e = i; e < n && e < i + 4; ++e) {
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
     if (!live) return;
     const f32x4v g0 = gi + gt;
     if (grad_out != nullptr) {             // data-parallel split: gradient only, the update follows the all-reduce
-        *reinterpret_cast<f32x4v*>(grad_out + i) = g0;
+        store_out_f32x4(grad_out + i, g0, o.plain);
         return;
     }
 #pragma unroll
@@ -1071,15 +1071,16 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
         opt_update(o, g0[j], a, b, c);
         p0[j] = a; m0[j] = b; v0[j] = c;
     }
-    *reinterpret_cast<f32x4v*>(p + i) = p0;
-    *reinterpret_cast<f32x4v*>(m + i) = m0;
-    if (o.kind != UMLH_OPT_SGD) *reinterpret_cast<f32x4v*>(v + i) = v0;
+    store_out_f32x4(p + i, p0, o.plain);
+    store_out_f32x4(m + i, m0, o.plain);
+    if (o.kind != UMLH_OPT_SGD) store_out_f32x4(v + i, v0, o.plain);
     if (shadow != nullptr) {
         const int cls = (int)(i / K), k = (int)(i % K);
         const long long piece = ((long long)(k >> 4) * (cpad / 32) + (cls >> 5)) * 64 + (cls & 31) + 32 * ((k >> 3) & 1);
         typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
         const u32x2s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3])};
-        *reinterpret_cast<u32x2s*>(shadow + piece * 8 + (k & 7)) = w;
+        if (o.plain) *reinterpret_cast<u32x2s*>(shadow + piece * 8 + (k & 7)) = w;
+        else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(shadow + piece * 8 + (k & 7)), "v"(w) : "memory");
     }
 }
 
@@ -1201,7 +1202,8 @@ static size_t fwd_smem_bytes(int ctw, int wc) {
             if (e != hipSuccess) return (int)e;                                                     \
             attr_done |= 1ULL << (dev_ & 63);                                                       \
         }                                                                                           \
-        hipLaunchKernelGGL((fwd_ce_f32<CT, W, F>), dim3(grid), dim3(512), sm, stream, *a);          \
+        FwdArgs c_ = *a; c_.plain = umlh_plain_stores();                                            \
+        hipLaunchKernelGGL((fwd_ce_f32<CT, W, F>), dim3(grid), dim3(512), sm, stream, c_);          \
         return (int)hipGetLastError();                                                              \
     }
 #define FWD_CASE(CT, W) FWD_CASE_F(CT, W, true) FWD_CASE_F(CT, W, false)
@@ -1241,6 +1243,7 @@ int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStrea
         }
         GemmArgs a = *g;
         a.slab_count = splits;
+        a.plain = umlh_plain_stores();
         hipLaunchKernelGGL(dw_f32, dim3(((g->N + 127) / 128) * ((g->M + 127) / 128) * splits), dim3(256), DW_SMEM, stream, a);
         return (int)hipGetLastError();
     }
@@ -1250,7 +1253,9 @@ int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStrea
     const int tm = (tm_env == 1 || tm_env == 2) ? tm_env : (wg128 < 768 ? 1 : 2);
     const int t = 64 * tm;
     dim3 grid((g->N + t - 1) / t, (g->M + t - 1) / t, splits);
-#define GEMM_CASE(A_, B_, T_) if (ta == A_ && tb == B_ && tm == T_) { hipLaunchKernelGGL((gemm_f32<A_, B_, T_>), grid, dim3(256), 0, stream, *g); return (int)hipGetLastError(); }
+    GemmArgs c = *g;
+    c.plain = umlh_plain_stores();
+#define GEMM_CASE(A_, B_, T_) if (ta == A_ && tb == B_ && tm == T_) { hipLaunchKernelGGL((gemm_f32<A_, B_, T_>), grid, dim3(256), 0, stream, c); return (int)hipGetLastError(); }
     GEMM_CASE(0, 0, 1) GEMM_CASE(0, 0, 2) GEMM_CASE(0, 1, 1) GEMM_CASE(0, 1, 2) GEMM_CASE(1, 1, 1) GEMM_CASE(1, 1, 2)
     return (int)hipErrorInvalidValue;
 }
@@ -1316,7 +1321,9 @@ int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride
     if (dg) d = *dg; else { d.dst = nullptr; d.n_slabs_img = n_slabs; d.inv_w0 = d.inv_w1 = 0.f; d.part = nullptr; d.ticket = nullptr; }
     if (d.dst && (!d.part || !d.ticket)) return (int)hipErrorInvalidValue;
     if (d.n_slabs_img > n_slabs) d.n_slabs_img = n_slabs;
-    hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, *o,
+    OptArgs oc = *o;
+    oc.plain = umlh_plain_stores();
+    hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, oc,
                        (unsigned short*)shadow, cpad, *f, grad_out, d);
     return (int)hipGetLastError();
 }
