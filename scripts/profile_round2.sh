@@ -36,4 +36,16 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/${tag}_kt_mb -o kt -- python3 $root/scripts/bench_multibench.py 40 100 > $root/$o/${tag}_kt_mb.log 2>&1
 cd $root
 python scripts/summarize_rocprof.py $(dirname $(find $o/${tag}_kt_mb -name "kt_kernel_stats.csv" | head -1)) kt $o/${tag}_multibench_kernel_stats_after.md "Command: rocprofv3 --kernel-trace --stats -- python3 scripts/bench_multibench.py 40 100 (z = 40, T = 50, B = 32, train mode; >= 1 s warm-up + 100 timed steps; 2 multi_opt_kernel launches per step)" > /dev/null
+# wide heads on the micro path (6 and 8 chunks: optimizer moments in memory), the opt-in 2-D forward, write-through stores A/B
+: > $o/${tag}_micro_wide_heads.txt
+for a in "32 bf16 3 768 100" "32 fp32 3 768 100" "32 bf16 3 768 1000" "32 bf16 3 1024 100" "32 fp32 3 1024 100" "32 bf16 3 512 100"; do
+  echo "== scripts/small_step_timing.py $a" >> $o/${tag}_micro_wide_heads.txt
+  python scripts/small_step_timing.py $a 2>&1 | grep "rep " >> $o/${tag}_micro_wide_heads.txt
+done
+echo "== UMLH_BF16_FWD2D=1 (fwd_ce_bf16_q)" > $o/${tag}_fwd2d_stamps.txt
+UMLH_BF16_FWD2D=1 python scripts/fwd_stamps.py >> $o/${tag}_fwd2d_stamps.txt 2>&1
+echo "== default (fwd_ce_bf16)" >> $o/${tag}_fwd2d_stamps.txt
+UMLH_BF16_FWD2D=0 python scripts/fwd_stamps.py >> $o/${tag}_fwd2d_stamps.txt 2>&1
+UMLH_BF16_FWD2D=1 python bench.py --no-cpu-baseline --no-fp32-leg 2>/dev/null | tail -1 > $o/${tag}_bench_fwd2d_on.json
+UMLH_WT=0 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $o/${tag}_bench_plain_stores.json
 tail -2 $o/${tag}_bench.json | cut -c1-600
