@@ -20,6 +20,16 @@
  *   - features are row-major fp32 [rows, dim]; labels are int64 (torch.long);
  *     optional `index` (int64) gathers rows from a device-resident table, which
  *     replaces the DataLoader collate of finetune.py:33-39,165-172.
+ *
+ * Environment switches read by the library (tuning / analysis; defaults are the measured-fastest settings):
+ *   UMLH_WT=0            plain instead of write-through (sc1) stores for what a kernel hands to the next launch
+ *   UMLH_BF16_FWD2D=1    bf16 mode: the 2-D forward (128-row tiles x 256-class groups, in-launch softmax merge); slower at cfg2
+ *   UMLH_BF16_STW=2      bf16 mode: two sample tiles per wave of the 1-D forward
+ *   UMLH_MICRO=0         never take the single-launch micro step
+ *   UMLH_F32_DW=0        fp32 dW through the generic GEMM instead of dw_f32
+ *   UMLH_ENC_GRAPH=0 / UMLH_ENC_FORK=1   encoder plans: no HIP-graph replay / weight-gradient work on a forked branch
+ *   UMLH_FORCE_DP=1      take the data-parallel split step (grad -> all-reduce -> update) with one rank
+ *   UMLH_DBG_FWD / UMLH_DBG_DW / UMLH_DBG_MICRO   in-kernel cycle stamps (scripts/fwd_stamps.py, dw_stamps.py, micro_stamps.py)
  */
 #ifndef UMLH_H
 #define UMLH_H
