@@ -173,6 +173,16 @@ def main():
         tab_i, tab_t = img_src.table(precision), txt_src.table(precision)
         engine.bind_tables(tab_i, tab_t)
         c_level_dp = world == 1 and args.force_dp_path and not args.dp_host_loop
+        watchdog = None
+        if world > 1:
+            # a communicator init or a collective that never completes (a rank missing) would otherwise hold the job until
+            # the caller's own limit: fail fast and say where.  Covers the RCCL attach below and the untimed warm-up.
+            import threading
+            state = {"loop": "communicator setup"}
+            watchdog = threading.Timer(180.0, lambda: (print(f"[rank {rank}] data-parallel {state['loop']} did not finish in 180 s; aborting",
+                                                                 file=sys.stderr, flush=True), os._exit(4)))
+            watchdog.daemon = True
+            watchdog.start()
         if world > 1 and not rehearsal and not args.dp_host_loop:
             # every rank must take the same loop: a rank whose communicator could not be created (library missing, init
             # error) sends the whole job to the per-step torch.distributed path instead of leaving the others in a collective
@@ -186,6 +196,8 @@ def main():
             c_level_dp = bool(int(flag.item()))
             if ok and not c_level_dp:
                 engine.detach_comm()
+        if watchdog is not None:
+            state["loop"] = "warm-up (%s)" % ("C-level RCCL loop" if c_level_dp else "per-step torch.distributed")
 
         def slot(m):
             if cursor["k"] + m > ring:
@@ -230,16 +242,6 @@ def main():
                 done += m
             return rows
 
-        watchdog = None
-        if world > 1:
-            # a collective that never completes (a rank missing from the communicator) would otherwise hold the job until
-            # the caller's own limit: fail fast and say where
-            import threading
-            watchdog = threading.Timer(180.0, lambda: (print(f"[rank {rank}] data-parallel warm-up did not finish in 180 s "
-                                                                 f"({'C-level RCCL loop' if c_level_dp else 'per-step torch.distributed'}); aborting",
-                                                                 file=sys.stderr, flush=True), os._exit(4)))
-            watchdog.daemon = True
-            watchdog.start()
         run_steps(prime)
         run_steps(warmup)
         if watchdog is not None:
