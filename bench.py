@@ -284,6 +284,11 @@ def main():
                 "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
                 "kernel_ms_source": "HIP events on the step's stream, raw intervals, mean of %d instrumented steps" % nprof,
                 "step_frac_of_mfma_roof": round((sum(flops.values()) / (PEAK[precision] * 1e12)) / (dt / steps), 4)}
+        if "proj_bwd" in acc:
+            # cfg2 has no img_proj: the proj_bwd interval holds NO kernel, so it reads what one pair of event markers costs on
+            # this stream; every kernel interval above carries about half of it (rocprofv3's trace of the same kernels:
+            # profiles/r02_kernel_stats.md).  Reported beside the raw intervals, never subtracted from them.
+            roof["empty_interval_ms"] = round(acc["proj_bwd"], 4)
         if precision == "bf16":
             pmc, src = latest_pmc()
             key = {"fwd_ce": "fwd_ce_bf16", "dw_head": "dw_bf16"}[dom]
