@@ -38,8 +38,7 @@ if os.environ.get("UMLH_BF16_FWD2D", "") != "0":
     for w in range(8):
         r = rel[:, w, [0, 1, 2, 3, 4, 5]].mean(dim=0)
         print(f"  {w}  " + "  ".join(f"{v:9.0f}" for v in r.tolist()))
-    print("workgroup duration: mean %.0f max %.0f cycles; start spread over workgroups %.0f" % (
-        rel[:, :, 5].max(dim=1).values.mean(), rel[:, :, 5].max(), (t0.max() - t0.min())))
+    print("workgroup duration: mean %.0f max %.0f cycles" % (rel[:, :, 5].max(dim=1).values.mean(), rel[:, :, 5].max()))
     for qq in range(4):
         print(f"class group {qq}: loop_end {rel[qq::4, :, 2].mean():.0f}  merge_done {rel[qq::4, :, 4].mean():.0f}  end {rel[qq::4, :, 5].mean():.0f}")
     sys.exit(0)
