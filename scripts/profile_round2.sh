@@ -14,8 +14,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/${tag}_kt -o kt -- python3 $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $root/$o/${tag}_kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/$o/${tag}_pmc_f -o pmc -- python3 $root/bench.py --steps 20 --warmup 3 --repeats 3 --prime 20 --no-cpu-baseline --no-fp32-leg > $root/$o/${tag}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/$o/${tag}_pmc_w -o pmc -- python3 $root/bench.py --steps 20 --warmup 3 --repeats 3 --prime 20 --no-cpu-baseline --no-fp32-leg > $root/$o/${tag}_pmc_w.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $root/$o/${tag}_pmc_sq -o pmc -- python3 $root/bench.py --steps 20 --warmup 3 --repeats 3 --prime 20 --no-cpu-baseline --no-fp32-leg > $root/$o/${tag}_pmc_sq.log 2>&1
 cd $root
 python scripts/summarize_rocprof.py $(dirname $(find $o/${tag}_kt -name "kt_kernel_stats.csv" | head -1)) kt $o/${tag}_kernel_stats.md "Command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline (bf16 headline + fp32 parity leg; cfg2; MI355X; scripts/profile_round2.sh)" > /dev/null
+python scripts/make_sq_json.py $(find $o/${tag}_pmc_sq -name "*counter_collection.csv" | head -1) $o/${tag}_bf16_sq.json > /dev/null
 python scripts/make_pmc_json.py $(find $o/${tag}_pmc_f -name "*counter_collection.csv" | head -1) $(find $o/${tag}_pmc_w -name "*counter_collection.csv" | head -1) $o/${tag}_bf16_pmc.json > /dev/null
 # micro step: per-phase stamps, step time, sweeps
 python scripts/micro_stamps.py 512 100 32 4096 > $o/${tag}_micro_stamps.txt 2>&1
