@@ -23,6 +23,7 @@
  *
  * Environment switches read by the library (tuning / analysis; defaults are the measured-fastest settings):
  *   UMLH_WT=0            plain instead of write-through (sc1) stores for what a kernel hands to the next launch
+ *   UMLH_BF16_FUSE=0     bf16 mode, linear head: forward and dW as two launches instead of one (fwd_dw_bf16)
  *   UMLH_BF16_FWD2D=1    bf16 mode: the 2-D forward (128-row tiles x 256-class groups, in-launch softmax merge); slower at cfg2
  *   UMLH_BF16_STW=2      bf16 mode: two sample tiles per wave of the 1-D forward
  *   UMLH_MICRO=0         never take the single-launch micro step

@@ -5,11 +5,17 @@ usage: make_sq_json.py <counter_collection.csv> <out.json>"""
 import csv, json, sys
 from collections import defaultdict
 
-KERNELS = {"fwd_ce_bf16": "fwd_ce_bf16", "dw_bf16": "dw_bf16", "head_step_kernel": "head_step"}
+KERNELS = {"fwd_dw_bf16": "fwd_dw_bf16", "fwd_ce_bf16": "fwd_ce_bf16", "dw_bf16": "dw_bf16", "head_step_kernel": "head_step"}
+
+
+def _is(pat, name):
+    """kernel-name match on a whole identifier (dw_bf16 must not match fwd_dw_bf16)"""
+    import re
+    return re.search(r"(^|[^_A-Za-z0-9])" + re.escape(pat), name) is not None
 acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     for k, pat in KERNELS.items():
-        if pat in r["Kernel_Name"]:
+        if _is(pat, r["Kernel_Name"]):
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"_note": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT "
                 "SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -- python3 bench.py --steps 20 --warmup 3 --repeats 3 --prime 20 --no-cpu-baseline --no-fp32-leg "

@@ -48,11 +48,14 @@ def _rb(x, y, idx=None):
                                                  (512, 1000, 300, 257, 100.0, 1), (512, 1000, 300, 257, 100.0, 2), (1024, 1000, 70, 300, 100.0, 1),
                                                  (384, 397, 40, 0, 50.0, 1), (256, 37, 0, 90, 20.0, 1),
                                                  (512, 1000, 300, 257, 100.0, "q"), (512, 1000, 0, 129, -100.0, "q"), (256, 600, 260, 200, 50.0, "q"),
-                                                 (512, 300, 130, 0, 100.0, "q"), (256, 1024, 128, 128, 30.0, "q")])
+                                                 (512, 300, 130, 0, 100.0, "q"), (256, 1024, 128, 128, 30.0, "q"),
+                                                 (512, 1000, 300, 257, 100.0, "f"), (128, 100, 50, 64, 100.0, "f"), (256, 37, 0, 90, 20.0, "f"),
+                                                 (384, 397, 40, 0, 50.0, "f"), (1024, 1000, 70, 300, -100.0, "f")])
 def test_bf16_grad_step_vs_oracle_on_rounded_operands(d, C, bi, bt, scale, stw, monkeypatch):
     import umlh
-    monkeypatch.setenv("UMLH_BF16_STW", "1" if stw == "q" else str(stw))
+    monkeypatch.setenv("UMLH_BF16_STW", "1" if stw in ("q", "f") else str(stw))
     monkeypatch.setenv("UMLH_BF16_FWD2D", "1" if stw == "q" else "0")
+    monkeypatch.setenv("UMLH_BF16_FUSE", "1" if stw == "f" else "0")      # "f": forward and dW as ONE launch (granule-gated dW blocks)
     rng = np.random.default_rng(d + C)
     xi, yi, xt, yt, w = _case(rng, d, C, 400, 350, scale)
     ii = rng.permutation(400)[:bi] if bi else None
@@ -245,6 +248,37 @@ def test_bf16_training_accuracy_parity_with_fp32():
     print(f"top-1 fp32 {accs['fp32']:.4f}  bf16 {accs['bf16']:.4f}  diff {100 * (accs['bf16'] - accs['fp32']):+.3f} pp")
     assert accs["fp32"] > 0.5
     assert abs(accs["bf16"] - accs["fp32"]) <= 0.001
+
+
+def test_bf16_single_launch_forward_dw_equals_two_launches_bit_for_bit(monkeypatch):
+    """UMLH_BF16_FUSE=1 (forward and dW as one launch, dW blocks gated on the forward blocks' granules, dZ^T read with
+    device-coherent loads): the arithmetic and its order are those of the two-launch step, so 40 AdamW steps on changing
+    batches (the same dZ^T addresses rewritten every step -- a stale L2 line would show) end in identical weights, moments
+    and scalars."""
+    import umlh
+    rng = np.random.default_rng(3)
+    d, C, n = 512, 1000, 6000
+    xi, yi, xt, yt, w = _case(rng, d, C, n, 3000, 100.0)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("UMLH_BF16_FUSE", mode)
+        e = _engine(w.copy(), 100.0, 1024, 1024, "bf16")
+        bi_t, bt_t = _rb(xi, yi), _rb(xt, yt)
+        bi_t.feats_bf16, bt_t.feats_bf16 = umlh.to_bf16(bi_t.feats), umlh.to_bf16(bt_t.feats)
+        g = torch.Generator().manual_seed(9)
+        scal = torch.zeros(40, umlh.N_SCALARS, device=DEV) if hasattr(umlh, "N_SCALARS") else None
+        for k in range(40):
+            ii = torch.randint(0, n, (1024 if k % 3 else 700,), generator=g).to(DEV)
+            ti = torch.randint(0, 3000, (1024 if k % 4 else 333,), generator=g).to(DEV)
+            e.train_step(umlh.RowBatch(bi_t.feats, bi_t.labels, ii, feats_bf16=bi_t.feats_bf16),
+                         umlh.RowBatch(bt_t.feats, bt_t.labels, ti, feats_bf16=bt_t.feats_bf16), lr=1e-3, step=k + 1,
+                         scalars_out=None if scal is None else scal[k])
+        torch.cuda.synchronize()
+        out[mode] = (e.w_head.clone(), e.m_head.clone(), e.v_head.clone(), None if scal is None else scal.clone())
+    for a, b in zip(out["0"], out["1"]):
+        if a is not None:
+            assert torch.equal(a, b)
+    assert torch.isfinite(out["1"][0]).all()
 
 
 def test_bf16_two_layer_head_split_step_equals_fused_step():

@@ -40,6 +40,8 @@ int umlh_launch_iota(long long* dst, long long n, hipStream_t stream);
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
 int umlh_bf16_launch_fwd_q(const FwdArgsB* a, int nq, int tiles, hipStream_t stream);
+int umlh_bf16_launch_fwd_dw(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
+                            unsigned epoch, int ts, int total_cols, hipStream_t stream);
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream);
 int umlh_enc_launch_bias_act(float* y, const float* b, long long M, int N, int relu, hipStream_t st);
 int umlh_enc_launch_relu_bwd(const float* y, float* dy, long long n, hipStream_t st);
@@ -73,7 +75,7 @@ static int fail(int code, const char* fmt, ...) {
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 struct Layout {                 // workspace partition, in floats from the base
-    long long dzt, h, dht, slabs_head, slabs_proj, partials, diag_part, grads, w16, iota, zeros, dbg, wpt16, wht16, xch, total;
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, diag_part, grads, w16, iota, zeros, dbg, wpt16, wht16, xch, fuse_flags, total;
     int fwd_nq;                 // bf16 2-D forward (fwd_ce_bf16_q): class groups per row tile, 0 = the 1-D kernel
     long long mc_flags, mc_xchg, mc_ext, mc_tab, mc_desc;   // micro-step region (umlh_kernels_micro.hip); mc_flags = 0: unsupported shape
     int mc_nwg, mc_nch, mc_cw;
@@ -174,6 +176,8 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
             L.xch = take(2LL * (L.ldz / 128 + 2) * nq * 4 * 128);      // 8-byte granules
         }
     }
+    // single-launch forward + dW (fwd_dw_bf16): one granule per forward block
+    L.fuse_flags = c.precision == UMLH_PREC_BF16 && !c.has_proj ? take(2LL * (L.max_blocks + 8)) : 0;
     // micro-step path: linear head whose width has a supported chunking (bf16 operand mode: widths that are multiples of 128)
     L.mc_flags = L.mc_xchg = L.mc_ext = L.mc_tab = L.mc_desc = 0;
     L.mc_nwg = (c.num_classes + UMLH_MICRO_CS - 1) / UMLH_MICRO_CS;
@@ -198,6 +202,8 @@ struct umlh_handle_s {
     int ctw, wc, ts;            // fwd_ce tile configuration
     int stw;                    // bf16: 32-sample tiles per wave
     unsigned fwd_epoch;         // bf16 2-D forward: launch tag of the exchange granules
+    unsigned fuse_epoch;        // single-launch forward + dW: launch tag of the forward blocks' granules
+    int fuse;                   // forward and dW of a linear bf16 head as one launch (default; UMLH_BF16_FUSE=0: two launches)
     // state carried from umlh_grad_step to umlh_apply_update
     int last_rows_img, last_rows_txt;
     bool iota_ready;            // bf16: identity row-id table in the workspace initialised
@@ -308,6 +314,8 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
         if (L.fwd_nq) h->ts = 128;
     }
     h->fwd_epoch = 0;
+    h->fuse_epoch = 0;
+    { const char* e = getenv("UMLH_BF16_FUSE"); h->fuse = (e && atoi(e) == 0) ? 0 : 1; }   // default on; =0: two launches
     h->last_rows_img = h->last_rows_txt = 0;
     h->global_rows_img = h->global_rows_txt = 0;
     h->profiling = false;
@@ -402,6 +410,12 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
         DeviceGuard dg_(h->device);
         const long long np = 4 * ((h->L.n_head + 1023) / 1024 + 2);
         if (hipMemset(ws(h, h->L.diag_part) + np, 0, 64 * sizeof(float)) != hipSuccess) return fail(UMLH_E_HIP, "umlh_bind: clearing the diagnostics ticket failed");
+    }
+    if (h->L.fuse_flags) {        // granules of the single-launch forward + dW: tag 0 = never written
+        DeviceGuard dg_(h->device);
+        if (hipMemset(ws(h, h->L.fuse_flags), 0, sizeof(float) * 2 * (size_t)(h->L.max_blocks + 8)) != hipSuccess)
+            return fail(UMLH_E_HIP, "umlh_bind: clearing the forward granules failed");
+        h->fuse_epoch = 0;
     }
     if (h->L.fwd_nq) {            // exchange granules of the 2-D forward: tag 0 = never written
         DeviceGuard dg_(h->device);
@@ -928,7 +942,12 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             fb.wtiles = cpad / 32;
             fb.ntiles = nb0 + nb1;
             HIPCHK(umlh_bf16_launch_fwd_q(&fb, L.fwd_nq, nb0 + nb1, st), "fwd_ce_bf16_q");
-        } else
+        }
+        // forward + dW as one launch (linear head, 1-D forward, write-through stores).  In profiling mode the interval
+        // mark 1 -> 2 is then empty and mark 2 -> 3 holds the one launch.
+        const bool fused = h->fuse && want_grad && !proj && !L.fwd_nq && h->stw == 1 && L.fuse_flags &&
+                           !umlh_plain_stores() && fb.dbg == 0 && h->dbg_dw == 0;
+        if (!L.fwd_nq && !fused)
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
         mark(h, 2, st);
         *n_slabs_head = 0; *n_slabs_proj = 0;
@@ -952,6 +971,12 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             g.M = c.num_classes; g.N = c.d_shared; g.K = r0p + r1p;
             g.k_chunk = sp.chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
             g.nsplit = splits; g.nsplit1 = sp.n_img; h->n_slabs_img = sp.n_img;
+            if (fused) {
+                if (++h->fuse_epoch == 0) h->fuse_epoch = 1;
+                HIPCHK(umlh_bf16_launch_fwd_dw(&fb, h->ctw, h->wc, nb0 + nb1, &g, splits,
+                                               reinterpret_cast<unsigned long long*>(ws(h, L.fuse_flags)), h->fuse_epoch, TS,
+                                               (nb0 + nb1) * TS, st), "fwd_dw_bf16");
+            } else
             HIPCHK(umlh_bf16_launch_dw(&g, splits, 0, 0, st), "dw_bf16");
             *n_slabs_head = splits;
         }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void transpose_shadow_kernel(const float* __re
 // 16 KiB in flight per wave).  Shared operand X: the block's TS sample rows stay resident in LDS
 // for a K-block of XK and every wave reads its B fragment with one ds_read_b128 per k-step.
 template <int CTW, int WC, int STW>
-__global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
+__device__ __forceinline__ void fwd_ce_bf16_body(const FwdArgsB& a, const int bid, unsigned char* smem_raw) {
     constexpr int WS = 8 / WC;
     constexpr int CPAD = 32 * CTW * WC;
     constexpr int TS = 32 * STW * WS;
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     constexpr int XRS = XK + 8;                                  // row stride (shorts): odd multiple of 16 B
     constexpr int PD = STW == 1 ? 8 : 4;                         // k-steps of W fragments in flight (ring depth)
     constexpr int NPX = (TS * (XK / 8)) / 512;                   // 16-B pieces of the X block per thread
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xt = reinterpret_cast<u16*>(smem_raw);                  // [TS][XRS]
     constexpr int STAGE_BYTES = 8 * CTW * 32 * 80;               // dZ staging: 8 waves x [CTW*32 rows][80 B (64 data + 16 pad)]
     constexpr int XT_BYTES = TS * XRS * 2;
@@ -160,11 +159,11 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave % WC, ws = wave / WC;
     const int h = lane >> 5, l31 = lane & 31;
-    const int sidx = (int)blockIdx.x >= a.seg[1].blk0 ? 1 : 0;
+    const int sidx = bid >= a.seg[1].blk0 ? 1 : 0;
     const SegDescB& sg = a.seg[sidx];
-#define STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)bid * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     STAMP(0);
-    const int row0 = ((int)blockIdx.x - sg.blk0) * TS;
+    const int row0 = (bid - sg.blk0) * TS;
     const int C = a.C, K = a.K;
 
     // X pieces of this thread: piece p -> row p / (XK/8), 16-B column p % (XK/8).  Rows past the
@@ -521,11 +520,17 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
         float l = 0.f, c = 0.f, g = 0.f;
 #pragma unroll
         for (int w = 0; w < WS; ++w) { l += red2[w * 4 + 0]; c += red2[w * 4 + 1]; g += red2[w * 4 + 2]; }
-        float* o = a.partials + (size_t)blockIdx.x * 4;
+        float* o = a.partials + (size_t)bid * 4;
         o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
     }
     STAMP(5);
 #undef STAMP
+}
+
+template <int CTW, int WC, int STW>
+__global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    fwd_ce_bf16_body<CTW, WC, STW>(a, (int)blockIdx.x, smem_dyn);
 }
 
 // --------------------------------------------------------------------------- //
@@ -889,12 +894,24 @@ constexpr int DMASK = (int)0x80000000;
 // 512 threads = 8 waves (2 along M x 4 along N, 64x32 outputs each): two waves per SIMD, so one
 // wave's address arithmetic / LDS traffic overlaps the other's MFMAs (with 4 waves per CU every
 // phase of a chunk was serialised: 2.9k VALU instructions per wave and 22 us measured).
-template <int AM, int OM>
-__global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
+// GATED (the single-launch forward + dW below): the dZ^T loads wait until the forward blocks that write this split's columns
+// have published their granules; everything that does not depend on dZ^T (row ids, the first feature chunks) is issued first.
+// device-coherent (sc1) 16-byte load through a raw buffer descriptor: reads what another XCD's workgroup wrote through to memory
+// earlier in the SAME launch without invalidating this XCD's whole L2 (an acquire fence per gated workgroup did that 32 times
+// per XCD and cost +12 us per step); out-of-range offsets return zeros (the branch-free masking of the plain path's zero page)
+__device__ __forceinline__ u32x4 load_coherent_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 1 << 4 /* sc1 */);
+}
+
+struct DwGate { const unsigned long long* flags; unsigned epoch; int ts, total_cols; };
+constexpr int DW_LDS_BYTES = 2 * DBM * RSA * 2 + 2 * DKT * RSF * 2 + DIDS * 4;   // two A tiles, two F tiles, the split's row ids
+
+template <int AM, int OM, bool GATED>
+__device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, const DwGate& gate, unsigned char* lds) {
     // two LDS buffers: chunk c+1 is written while chunk c is consumed -> ONE barrier per chunk
-    __shared__ __attribute__((aligned(16))) u16 At[2][DBM * RSA];
-    __shared__ __attribute__((aligned(16))) u16 Ft[2][DKT * RSF];
-    __shared__ int ids[DIDS];
+    u16 (*At)[DBM * RSA] = reinterpret_cast<u16 (*)[DBM * RSA]>(lds);
+    u16 (*Ft)[DKT * RSF] = reinterpret_cast<u16 (*)[DKT * RSF]>(lds + 2 * DBM * RSA * 2);
+    int* ids = reinterpret_cast<int*>(lds + 2 * DBM * RSA * 2 + 2 * DKT * RSF * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int h = lane >> 5, l31 = lane & 31;
@@ -903,7 +920,7 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     // so split z = b % nsplit keeps every tile of one K-split -- which all re-read the same dZ^T
     // columns and feature rows -- on ONE XCD's L2 (speed only; any placement is correct).
     const int nx = (g.N + DBN - 1) / DBN;
-    const int bid = blockIdx.x;
+    const int bid = vbid;
     const int z = bid % g.nsplit, t = bid / g.nsplit;
     const int m0 = (t / nx) * DBM, n0 = (t % nx) * DBN;
     // modality-aligned split-K: slabs [0, nsplit1) cover the image rows [0, k_switch), the rest the text
@@ -917,7 +934,7 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-#define DSTAMP(i) do { if (g.stamps && lane == 0) g.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define DSTAMP(i) do { if (g.stamps && lane == 0) g.stamps[((size_t)vbid * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     DSTAMP(0);
 
     struct Stage { u32x4 a[2]; u32x4 f[2]; };
@@ -939,16 +956,24 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
         f_col[q] = (col >> 6) * g.bcs + (col & 63);     // row-major rows: bcs = 64 -> col
         f_colok[q] = n0 + 8 * (p & 15) < g.N;
     }
+    // GATED: dZ^T comes through a buffer descriptor with device-coherent loads (AM == 0 only)
+    __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(g.A), 0, GATED ? (int)(((size_t)(g.K + 63) / 64) * g.lda * 128) : 0, 0x00020000);
+    auto a_load = [&](int q, int k0, size_t achunk) -> u32x4 {
+        const bool on = k0 + a_col[q] < ke && !UMLH_ABL(g.dbg & 1);
+        if (GATED) {
+            const unsigned off = (unsigned)((a_thr[q] - g.A + achunk) * 2);
+            return load_coherent_b128(a_rsrc, on ? off : 0xfffffff0u);
+        }
+        const u16* ap = on ? a_thr[q] + achunk : g.zeros;
+        return *reinterpret_cast<const u32x4*>(ap);
+    };
     // Branch-free loads: masked pieces read a zero page (a select on the loaded value would make the
     // compiler wait for the load right here and serialise the pipeline).
     auto gloadA = [&](Stage& sg, int c) {
         const int k0 = kb + c * DKT;
         const size_t achunk = AM == 0 ? (size_t)(k0 >> 6) * g.lda * 64 : (size_t)k0;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const u16* ap = (k0 + a_col[q] < ke && !UMLH_ABL(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
-            sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
-        }
+        for (int q = 0; q < 2; ++q) sg.a[q] = a_load(q, k0, achunk);
     };
     auto gloadF = [&](Stage& sg, int c) {
         const int k0 = kb + c * DKT;                    // whole chunk lies in one modality (k_switch % 64 == 0)
@@ -997,8 +1022,10 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     // masked (padding / out-of-range) row.  The id-independent dZ^T loads of the first DNS chunks are
     // issued first so their latency overlaps this round trip.
     const int lastc = nchunks - 1;
+    if (!GATED) {
 #pragma unroll
-    for (int d = 0; d < DNS; ++d) gloadA(st[d], min(d, lastc));
+        for (int d = 0; d < DNS; ++d) gloadA(st[d], min(d, lastc));
+    }
     for (int i = tid; i < g.k_chunk; i += 512) {
         int k = kb + i;
         bool seg2 = k >= g.k_switch;
@@ -1012,6 +1039,33 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     DSTAMP(1);
 #pragma unroll
     for (int d = 0; d < DNS; ++d) gloadF(st[d], min(d, lastc));
+    if (GATED) {
+        // forward block b writes columns [b * ts, (b + 1) * ts) of dZ^T (image blocks first, text columns start at a multiple
+        // of ts); this split reads [kb, ke).  One sweep = all granules of the range in flight; bounded; a timed-out wait
+        // poisons the slab (NaN weights after the update) instead of hanging.
+        __shared__ int gate_bad;
+        if (tid == 0) gate_bad = 0;
+        if (wave == 0) {
+            const int b0 = kb / gate.ts, nb = (min(ke, gate.total_cols) - kb + gate.ts - 1) / gate.ts;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool bad = false;
+            for (unsigned spin = 0; !bad; ++spin) {
+                bool ok = true;
+                for (int i = lane; i < nb; i += 64) {
+                    const unsigned long long v = __hip_atomic_load(gate.flags + b0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(v >> 32) == gate.epoch;
+                }
+                if (__all(ok)) break;
+                if ((spin & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) bad = true;   // 2 s at 100 MHz
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (bad && lane == 0) gate_bad = 1;
+        }
+        __syncthreads();
+        if (gate_bad && tid == 0) g.out[(size_t)z * g.slab_stride] = __builtin_nanf("");
+#pragma unroll
+        for (int d = 0; d < DNS; ++d) gloadA(st[d], min(d, lastc));
+    }
     lstore(st[0], 0);                                   // chunk 0 -> buffer 0
     gload(st[0], min(DNS, lastc));
     __syncthreads();
@@ -1034,8 +1088,7 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
         const int k0 = kb + c * DKT;
         if (pc < 2) {
             const size_t achunk = AM == 0 ? (size_t)(k0 >> 6) * g.lda * 64 : (size_t)k0;
-            const u16* ap = (k0 + a_col[q] < ke && !UMLH_ABL(g.dbg & 1)) ? a_thr[q] + achunk : g.zeros;
-            sg.a[q] = *reinterpret_cast<const u32x4*>(ap);
+            sg.a[q] = a_load(q, k0, achunk);
         } else {
             const bool seg2 = k0 >= g.k_switch;
             const u16* fb = seg2 ? g.B2 : g.B;
@@ -1109,6 +1162,33 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     }
     DSTAMP(7);
 #undef DSTAMP
+}
+
+template <int AM, int OM>
+__global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
+    __shared__ __attribute__((aligned(16))) unsigned char dw_lds[DW_LDS_BYTES];
+    DwGate none = {nullptr, 0u, 32, 0};
+    dw_bf16_body<AM, OM, false>(g, (int)blockIdx.x, none, dw_lds);
+}
+
+// --------------------------------------------------------------------------- //
+// forward + dW as ONE launch: blocks [0, nfwd) are the forward's, blocks [nfwd, nfwd + ndw) dW's.  The dispatcher hands out
+// workgroups in block order per XCD and one workgroup fills a CU (134 KB of LDS), so a dW workgroup starts on a CU when its
+// forward workgroup retires and never before every forward workgroup of its XCD has been dispatched: the only waits are dW's,
+// on forward blocks that are running or done.  A forward block publishes an epoch-tagged granule once its write-through
+// dZ^T stores have drained (s_waitcnt vmcnt(0) in every wave, workgroup barrier, one sc1 store).
+// --------------------------------------------------------------------------- //
+template <int CTW, int WC>
+__global__ __launch_bounds__(512) void fwd_dw_bf16(FwdArgsB a, DwArgsB g, DwGate gate, unsigned long long* flags, int nfwd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    if ((int)blockIdx.x < nfwd) {
+        fwd_ce_bf16_body<CTW, WC, 1>(a, (int)blockIdx.x, smem_dyn);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) fq_store_granule(flags + blockIdx.x, gate.epoch, 1.f);
+    } else {
+        dw_bf16_body<0, 0, true>(g, (int)blockIdx.x - nfwd, gate, smem_dyn);   // the same dynamic LDS, laid out for dW
+    }
 }
 
 // --------------------------------------------------------------------------- //
@@ -1200,6 +1280,37 @@ int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, 
     if (mode == 0) hipLaunchKernelGGL((transpose_shadow_kernel<0>), grid, dim3(256), 0, stream, src, R, Cc, ldd, (u16*)dst);
     else hipLaunchKernelGGL((transpose_shadow_kernel<1>), grid, dim3(256), 0, stream, src, R, Cc, ldd, (u16*)dst);
     return (int)hipGetLastError();
+}
+
+#define FWD_DW_CASE(CT, W)                                                                                         \
+    if (ctw == CT && wc == W) {                                                                                    \
+        size_t sm = fwd_smem_bytes_b(CT, W, 1);                                                                    \
+        if (sm < (size_t)DW_LDS_BYTES) sm = DW_LDS_BYTES;                                                          \
+        static unsigned long long attr_done = 0;                                                                   \
+        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_dw_bf16<CT, W>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);               \
+            if (e != hipSuccess) return (int)e;                                                                    \
+            attr_done |= 1ULL << (dev_ & 63);                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL((fwd_dw_bf16<CT, W>), dim3(nfwd + ndw), dim3(512), sm, stream, fa, ga, gate, flags, nfwd); \
+        return (int)hipGetLastError();                                                                             \
+    }
+
+// forward (1-D kernel, one sample tile per wave) and dW (AM 0, OM 0) in one launch; see fwd_dw_bf16
+int umlh_bf16_launch_fwd_dw(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
+                            unsigned epoch, int ts, int total_cols, hipStream_t stream) {
+    if (nfwd <= 0 || g->M <= 0 || g->N <= 0 || !flags || epoch == 0 || !a->dzt) return (int)hipErrorInvalidValue;
+    if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
+    if (g->k_switch % DKT != 0 || g->bcs < 64 || g->N % 8 != 0 || umlh_plain_stores()) return (int)hipErrorInvalidValue;
+    const int ndw = ((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits;
+    FwdArgsB fa = *a; fa.plain = 0;
+    DwArgsB ga = *g; ga.plain = 0;
+    DwGate gate = {flags, epoch, ts, total_cols};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    FWD_DW_CASE(1, 1) FWD_DW_CASE(1, 2) FWD_DW_CASE(1, 4) FWD_DW_CASE(1, 8) FWD_DW_CASE(2, 8) FWD_DW_CASE(4, 8)
+    return (int)hipErrorInvalidValue;
 }
 
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream) {
