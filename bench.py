@@ -282,9 +282,15 @@ def main():
         fused = precision == "bf16" and os.environ.get("UMLH_BF16_FUSE", "1") != "0" and os.environ.get("UMLH_WT", "1") != "0" \
             and os.environ.get("UMLH_BF16_FWD2D", "0") != "1"
         if fused:
-            acc["fwd_dw"] = acc.pop("dw_head")
+            # UMLH_BF16_FUSE: 2 (default) = the update and the step scalars ride in the same launch too (single-GPU step only:
+            # the data-parallel split step keeps the update behind the all-reduce); 1 = forward + dW
+            whole = os.environ.get("UMLH_BF16_FUSE", "2") not in ("0", "1") and not dp_path
+            name = "step" if whole else "fwd_dw"
+            acc[name] = acc.pop("dw_head")
             acc["empty_interval_fwd"] = acc.pop("fwd_ce")
-            flops = {"fwd_dw": 2 * 2.0 * 2 * BATCH * C * D}
+            if whole:
+                acc["empty_interval_update"] = acc.pop("reduce_update")
+            flops = {name: 2 * 2.0 * 2 * BATCH * C * D}
         dom = max(flops, key=lambda n: acc[n])
         achieved = flops[dom] / (acc[dom] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[precision],
@@ -299,7 +305,7 @@ def main():
             roof["empty_interval_ms"] = round(acc["proj_bwd"], 4)
         if precision == "bf16":
             pmc, src = latest_pmc()
-            key = {"fwd_ce": "fwd_ce_bf16", "dw_head": "dw_bf16", "fwd_dw": "fwd_dw_bf16"}[dom]
+            key = {"fwd_ce": "fwd_ce_bf16", "dw_head": "dw_bf16", "fwd_dw": "fwd_dw_bf16", "step": "step_bf16"}[dom]
             if pmc and key in pmc:
                 roof["traffic"] = pmc[key].get("hbm_bytes_corrected")
                 roof["traffic_source"] = f"static: {src} (rocprofv3 --pmc passes, not collected in this run)"

@@ -23,7 +23,8 @@
  *
  * Environment switches read by the library (tuning / analysis; defaults are the measured-fastest settings):
  *   UMLH_WT=0            plain instead of write-through (sc1) stores for what a kernel hands to the next launch
- *   UMLH_BF16_FUSE=0     bf16 mode, linear head: forward and dW as two launches instead of one (fwd_dw_bf16)
+ *   UMLH_BF16_FUSE=2|1|0 bf16 mode, linear head: the whole step as one launch (step_bf16, default) | forward + dW as one
+ *                        launch (fwd_dw_bf16) + the update kernel | three launches
  *   UMLH_BF16_FWD2D=1    bf16 mode: the 2-D forward (128-row tiles x 256-class groups, in-launch softmax merge); slower at cfg2
  *   UMLH_BF16_STW=2      bf16 mode: two sample tiles per wave of the 1-D forward
  *   UMLH_MICRO=0         never take the single-launch micro step

@@ -6,7 +6,7 @@ algorithmic bytes of SURVEY 8(d).  usage: make_pmc_json.py <fetch.csv> <write.cs
 import csv, json, sys
 from collections import defaultdict
 
-KERNELS = {"fwd_dw_bf16": "fwd_dw_bf16", "fwd_ce_bf16": "fwd_ce_bf16", "dw_bf16": "dw_bf16", "head_step_kernel": "head_step"}
+KERNELS = {"step_bf16": "step_bf16", "fwd_dw_bf16": "fwd_dw_bf16", "fwd_ce_bf16": "fwd_ce_bf16", "dw_bf16": "dw_bf16", "head_step_kernel": "head_step"}
 
 
 def _is(pat, name):
@@ -14,6 +14,7 @@ def _is(pat, name):
     import re
     return re.search(r"(^|[^_A-Za-z0-9])" + re.escape(pat), name) is not None
 ALG = {  # cfg2, per launch (design bytes of each kernel; the SURVEY 8(d) per-STEP figure is 20.7 MB: rows 8.4 MB + AdamW 12.3 MB)
+    "step_bf16": (104_700_000, "the whole step in one launch: forward + dW + update rows below added"),
     "fwd_dw_bf16": (75_000_000, "forward + dW in one launch: the two rows below added (dZ^T written by the forward blocks and re-read by the dW blocks)"),
     "fwd_ce_bf16": (33_800_000, "8192 gathered bf16 rows x 1 KiB + W shadow 1 MiB x 8 XCD L2s + dZ^T 8192 x 1000 x 2 B written"),
     "dw_bf16": (41_200_000, "dZ^T 16.4 MB + 8192 feature rows 8.4 MB read once + 8 fp32 slabs x 2.05 MB written"),

@@ -5,7 +5,7 @@ usage: make_sq_json.py <counter_collection.csv> <out.json>"""
 import csv, json, sys
 from collections import defaultdict
 
-KERNELS = {"fwd_dw_bf16": "fwd_dw_bf16", "fwd_ce_bf16": "fwd_ce_bf16", "dw_bf16": "dw_bf16", "head_step_kernel": "head_step"}
+KERNELS = {"step_bf16": "step_bf16", "fwd_dw_bf16": "fwd_dw_bf16", "fwd_ce_bf16": "fwd_ce_bf16", "dw_bf16": "dw_bf16", "head_step_kernel": "head_step"}
 
 
 def _is(pat, name):

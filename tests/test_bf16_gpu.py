@@ -260,7 +260,7 @@ def test_bf16_single_launch_forward_dw_equals_two_launches_bit_for_bit(monkeypat
     d, C, n = 512, 1000, 6000
     xi, yi, xt, yt, w = _case(rng, d, C, n, 3000, 100.0)
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):       # separate launches / forward + dW as one / the whole step (update + scalars too) as one
         monkeypatch.setenv("UMLH_BF16_FUSE", mode)
         e = _engine(w.copy(), 100.0, 1024, 1024, "bf16")
         bi_t, bt_t = _rb(xi, yi), _rb(xt, yt)
@@ -275,10 +275,11 @@ def test_bf16_single_launch_forward_dw_equals_two_launches_bit_for_bit(monkeypat
                          scalars_out=None if scal is None else scal[k])
         torch.cuda.synchronize()
         out[mode] = (e.w_head.clone(), e.m_head.clone(), e.v_head.clone(), None if scal is None else scal.clone())
-    for a, b in zip(out["0"], out["1"]):
-        if a is not None:
-            assert torch.equal(a, b)
-    assert torch.isfinite(out["1"][0]).all()
+    for mode in ("1", "2"):
+        for a, b in zip(out["0"], out[mode]):
+            if a is not None:
+                assert torch.equal(a, b), mode
+    assert torch.isfinite(out["2"][0]).all()
 
 
 def test_bf16_two_layer_head_split_step_equals_fused_step():

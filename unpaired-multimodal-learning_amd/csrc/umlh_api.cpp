@@ -40,6 +40,8 @@ int umlh_launch_iota(long long* dst, long long n, hipStream_t stream);
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
 int umlh_bf16_launch_fwd_q(const FwdArgsB* a, int nq, int tiles, hipStream_t stream);
+int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
+                          unsigned epoch, int ts, int total_cols, const HeadFuse* hf, hipStream_t stream);
 int umlh_bf16_launch_fwd_dw(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
                             unsigned epoch, int ts, int total_cols, hipStream_t stream);
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream);
@@ -177,7 +179,7 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
         }
     }
     // single-launch forward + dW (fwd_dw_bf16): one granule per forward block
-    L.fuse_flags = c.precision == UMLH_PREC_BF16 && !c.has_proj ? take(2LL * (L.max_blocks + 8)) : 0;
+    L.fuse_flags = c.precision == UMLH_PREC_BF16 && !c.has_proj ? take(2LL * (L.max_blocks + 8 + 4096)) : 0;   // forward blocks, then dW blocks
     // micro-step path: linear head whose width has a supported chunking (bf16 operand mode: widths that are multiples of 128)
     L.mc_flags = L.mc_xchg = L.mc_ext = L.mc_tab = L.mc_desc = 0;
     L.mc_nwg = (c.num_classes + UMLH_MICRO_CS - 1) / UMLH_MICRO_CS;
@@ -204,6 +206,8 @@ struct umlh_handle_s {
     unsigned fwd_epoch;         // bf16 2-D forward: launch tag of the exchange granules
     unsigned fuse_epoch;        // single-launch forward + dW: launch tag of the forward blocks' granules
     int fuse;                   // forward and dW of a linear bf16 head as one launch (default; UMLH_BF16_FUSE=0: two launches)
+    const HeadFuse* pending_head;   // set by train_step_impl: the update may ride in the same launch (step_bf16)
+    bool head_fused_done;       // forward_backward took it
     // state carried from umlh_grad_step to umlh_apply_update
     int last_rows_img, last_rows_txt;
     bool iota_ready;            // bf16: identity row-id table in the workspace initialised
@@ -315,7 +319,8 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     }
     h->fwd_epoch = 0;
     h->fuse_epoch = 0;
-    { const char* e = getenv("UMLH_BF16_FUSE"); h->fuse = (e && atoi(e) == 0) ? 0 : 1; }   // default on; =0: two launches
+    h->pending_head = nullptr; h->head_fused_done = false;
+    { const char* e = getenv("UMLH_BF16_FUSE"); h->fuse = e ? atoi(e) : 2; }   // 2 (default): the whole step as one launch; 1: forward + dW as one; 0: separate launches
     h->last_rows_img = h->last_rows_txt = 0;
     h->global_rows_img = h->global_rows_txt = 0;
     h->profiling = false;
@@ -413,7 +418,7 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
     }
     if (h->L.fuse_flags) {        // granules of the single-launch forward + dW: tag 0 = never written
         DeviceGuard dg_(h->device);
-        if (hipMemset(ws(h, h->L.fuse_flags), 0, sizeof(float) * 2 * (size_t)(h->L.max_blocks + 8)) != hipSuccess)
+        if (hipMemset(ws(h, h->L.fuse_flags), 0, sizeof(float) * 2 * (size_t)(h->L.max_blocks + 8 + 4096)) != hipSuccess)
             return fail(UMLH_E_HIP, "umlh_bind: clearing the forward granules failed");
         h->fuse_epoch = 0;
     }
@@ -971,7 +976,16 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             g.M = c.num_classes; g.N = c.d_shared; g.K = r0p + r1p;
             g.k_chunk = sp.chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
             g.nsplit = splits; g.nsplit1 = sp.n_img; h->n_slabs_img = sp.n_img;
-            if (fused) {
+            const int ndw_blocks = ((c.d_shared + 127) / 128) * ((c.num_classes + 127) / 128) * splits;
+            if (fused && h->pending_head && ndw_blocks <= 4096 && h->fuse >= 2) {
+                if (++h->fuse_epoch == 0) h->fuse_epoch = 1;
+                HeadFuse hf = *h->pending_head;
+                hf.n_slabs = splits; hf.n_slabs_img = sp.n_img;
+                HIPCHK(umlh_bf16_launch_step(&fb, h->ctw, h->wc, nb0 + nb1, &g, splits,
+                                             reinterpret_cast<unsigned long long*>(ws(h, L.fuse_flags)), h->fuse_epoch, TS,
+                                             (nb0 + nb1) * TS, &hf, st), "step_bf16");
+                h->head_fused_done = true;
+            } else if (fused) {
                 if (++h->fuse_epoch == 0) h->fuse_epoch = 1;
                 HIPCHK(umlh_bf16_launch_fwd_dw(&fb, h->ctw, h->wc, nb0 + nb1, &g, splits,
                                                reinterpret_cast<unsigned long long*>(ws(h, L.fuse_flags)), h->fuse_epoch, TS,
@@ -1149,11 +1163,31 @@ static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_
     h->dp_diag = false;
     float* tail = ws(h, h->L.grads) + msg_tail_off(h);
     h->diag_dst = h->diagnostics ? (scalars_out ? scalars_out : tail + 2) + UMLH_N_CORE_SCALARS : nullptr;
-    int rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
-    if (rc) return rc;
+    const umlh_config_t& c = h->cfg;
     OptArgs o = make_opt(h->cfg, *hy);
     FinalizeArgs f = make_finalize(h, img, txt, hy, true, scalars_out, true);
-    const umlh_config_t& c = h->cfg;
+    // the update (and the step scalars) may ride in the forward + dW launch: linear bf16 head, no gradient diagnostics
+    // (in profiling mode the interval mark 2 -> 3 then holds the whole step and the others are empty)
+    HeadFuse hfuse;
+    memset(&hfuse, 0, sizeof(hfuse));
+    h->head_fused_done = false;
+    h->pending_head = nullptr;
+    if (c.precision == UMLH_PREC_BF16 && !c.has_proj && c.d_shared % 8 == 0 && !h->diag_dst) {
+        hfuse.slabs = ws(h, h->L.slabs_head); hfuse.slab_stride = h->L.n_head; hfuse.C = c.num_classes; hfuse.K = c.d_shared;
+        hfuse.p = h->buf.w_head; hfuse.m = h->buf.m_head; hfuse.v = h->buf.v_head;
+        hfuse.shadow = reinterpret_cast<unsigned short*>(ws(h, h->L.w16)); hfuse.cpad = 32 * h->ctw * h->wc;
+        hfuse.o = o; hfuse.f = f;
+        h->pending_head = &hfuse;
+    }
+    int rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
+    h->pending_head = nullptr;
+    if (rc) return rc;
+    if (h->head_fused_done) {
+        h->head_fused_done = false;
+        h->shadow_fresh = keep_shadow;
+        mark(h, 5, st);
+        return UMLH_OK;
+    }
     DiagArgs dg;
     dg.dst = h->diag_dst; dg.n_slabs_img = h->n_slabs_img;
     dg.part = ws(h, h->L.diag_part);

@@ -229,3 +229,75 @@ __device__ __forceinline__ void opt_update(const OptArgs& o, float g, float& p, 
         p = p + (o.neg_step_size * m) / denom;
     }
 }
+
+// Step scalars from the forward's per-block partials + the learnable logit scales' update (head_step_kernel's last block,
+// finalize_kernel, and the finalize block of the single-launch step).  Works in a 256- or a 512-thread block: only threads
+// < 256 touch data, every thread reaches every barrier; the summation order is the same in all callers.  COH: the partials
+// were written through by forward blocks of the SAME launch and are read with device-coherent loads.
+template <bool COH>
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& f, float (*sh)[256]) {
+    const int tid = threadIdx.x;
+    const bool on = tid < 256;
+    if (f.partials != nullptr) {
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (on)
+            for (int b = tid; b < f.nb0 + f.nb1; b += 256) {
+                const float* q = f.partials + (size_t)b * 4;
+                int o = b < f.nb0 ? 0 : 3;
+                if (COH) {
+                    s[o + 0] += __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s[o + 1] += __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s[o + 2] += __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    s[o + 0] += q[0]; s[o + 1] += q[1]; s[o + 2] += q[2];
+                }
+            }
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) sh[j][tid] = s[j];
+        }
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) sh[j][tid] += sh[j][tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            float* t = f.tail;
+            t[0] = sh[2][0] * f.w0 * f.inv_rows0;                    // d loss / d img_scale
+            t[1] = sh[5][0] * f.w1 * f.inv_rows1;                    // d loss / d txt_scale
+            float* sc = t + 2;
+            sc[UMLH_S_LOSS_IMG] = sh[0][0] * f.inv_rows0;
+            sc[UMLH_S_LOSS_TXT] = sh[3][0] * f.inv_rows1;
+            sc[UMLH_S_ACC_IMG] = sh[1][0] * f.inv_rows0;
+            sc[UMLH_S_ACC_TXT] = sh[4][0] * f.inv_rows1;
+            sc[UMLH_S_GSCALE_IMG] = t[0];
+            sc[UMLH_S_GSCALE_TXT] = t[1];
+            sc[UMLH_S_CORRECT] = sh[1][0] + sh[4][0];
+            sc[UMLH_S_LOSS_SUM] = sh[0][0] + sh[3][0];
+        }
+        __syncthreads();
+    }
+    if (tid < UMLH_N_CORE_SCALARS && f.scalars_out) f.scalars_out[tid] = f.tail[2 + tid];
+    if (tid < 2 && ((f.update_mask >> tid) & 1)) {
+        float p = f.scales[tid], m = f.m_scales[tid], v = f.v_scales[tid];
+        opt_update(f.opt, f.tail[tid], p, m, v);
+        f.scales[tid] = p; f.m_scales[tid] = m; f.v_scales[tid] = v;
+    }
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
+}
+
+// everything the head blocks of the single-launch step need (step_bf16 in umlh_kernels_bf16.hip)
+struct HeadFuse {
+    const float* slabs; int n_slabs, n_slabs_img; long long slab_stride; int C, K;
+    float* p; float* m; float* v; unsigned short* shadow; int cpad;
+    int n_sub;                   // 256-thread sub-blocks of the update (two per workgroup)
+    int dw_per_row;              // dW blocks per 128-class tile row (column tiles x K splits): the granules a sub-block waits for
+    OptArgs o; FinalizeArgs f;
+};

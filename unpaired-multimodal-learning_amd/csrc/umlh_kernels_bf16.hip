@@ -521,7 +521,7 @@ __device__ __forceinline__ void fwd_ce_bf16_body(const FwdArgsB& a, const int bi
 #pragma unroll
         for (int w = 0; w < WS; ++w) { l += red2[w * 4 + 0]; c += red2[w * 4 + 1]; g += red2[w * 4 + 2]; }
         float* o = a.partials + (size_t)bid * 4;
-        o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
+        store_out_f32(o + 0, l, a.plain); store_out_f32(o + 1, c, a.plain); store_out_f32(o + 2, g, a.plain); store_out_f32(o + 3, 0.f, a.plain);
     }
     STAMP(5);
 #undef STAMP
@@ -903,7 +903,7 @@ __device__ __forceinline__ u32x4 load_coherent_b128(__amdgpu_buffer_rsrc_t rsrc,
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 1 << 4 /* sc1 */);
 }
 
-struct DwGate { const unsigned long long* flags; unsigned epoch; int ts, total_cols; };
+struct DwGate { const unsigned long long* flags; unsigned epoch; int ts, total_cols; unsigned long long* publish; };   // publish: this launch's dW granules (or NULL)
 constexpr int DW_LDS_BYTES = 2 * DBM * RSA * 2 + 2 * DKT * RSF * 2 + DIDS * 4;   // two A tiles, two F tiles, the split's row ids
 
 template <int AM, int OM, bool GATED>
@@ -1161,13 +1161,18 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, c
             }
     }
     DSTAMP(7);
+    if (GATED && gate.publish != nullptr) {              // the update blocks of the same launch wait for this split's slab
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) fq_store_granule(gate.publish + vbid, gate.epoch, 1.f);
+    }
 #undef DSTAMP
 }
 
 template <int AM, int OM>
 __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     __shared__ __attribute__((aligned(16))) unsigned char dw_lds[DW_LDS_BYTES];
-    DwGate none = {nullptr, 0u, 32, 0};
+    DwGate none = {nullptr, 0u, 32, 0, nullptr};
     dw_bf16_body<AM, OM, false>(g, (int)blockIdx.x, none, dw_lds);
 }
 
@@ -1188,6 +1193,104 @@ __global__ __launch_bounds__(512) void fwd_dw_bf16(FwdArgsB a, DwArgsB g, DwGate
         if (threadIdx.x == 0) fq_store_granule(flags + blockIdx.x, gate.epoch, 1.f);
     } else {
         dw_bf16_body<0, 0, true>(g, (int)blockIdx.x - nfwd, gate, smem_dyn);   // the same dynamic LDS, laid out for dW
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// the whole step as ONE launch: forward blocks, dW blocks (as in fwd_dw_bf16), then the update blocks and the finalize block.
+// An update workgroup = two 256-thread sub-blocks of head_step_kernel's work (4 consecutive elements per thread, same
+// arithmetic in the same order); it loads W, m, v first, then waits for the granules of the dW blocks of its 128-class tile
+// row(s) (column tiles x K splits), reads their slabs with device-coherent loads, updates and writes through.  The last
+// workgroup waits for every forward block's granule and forms the step scalars / logit-scale update from the forward's
+// partials.  Waits only ever point at lower block ids, which the in-order dispatcher has started before.
+// --------------------------------------------------------------------------- //
+__device__ __forceinline__ bool sweep_granules(const unsigned long long* fl, int first, int count, unsigned epoch, int lane, int stride) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spin = 0;; ++spin) {
+        bool ok = true;
+        for (int i = lane; i < count; i += stride) {
+            const unsigned long long v = __hip_atomic_load(fl + first + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (unsigned)(v >> 32) == epoch;
+        }
+        if (__all(ok)) return true;
+        if ((spin & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) return false;   // 2 s at 100 MHz
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int CTW, int WC>
+__global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate gate, unsigned long long* flags, int nfwd, int ndw, HeadFuse hf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    const int bid = (int)blockIdx.x;
+    if (bid < nfwd) {
+        fwd_ce_bf16_body<CTW, WC, 1>(a, bid, smem_dyn);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) fq_store_granule(flags + bid, gate.epoch, 1.f);
+        return;
+    }
+    if (bid < nfwd + ndw) {
+        dw_bf16_body<0, 0, true>(g, bid - nfwd, gate, smem_dyn);
+        return;
+    }
+    float (*sh)[256] = reinterpret_cast<float (*)[256]>(smem_dyn);
+    if (bid == (int)gridDim.x - 1) {                         // finalize: needs every forward block's partials
+        __shared__ int fin_bad;
+        if (threadIdx.x == 0) fin_bad = 0;
+        __syncthreads();
+        if (!sweep_granules(flags, 0, nfwd, gate.epoch, (int)threadIdx.x & 63, 64)) fin_bad = 1;   // every wave sweeps (cheap, one block)
+        __syncthreads();
+        FinalizeArgs f = hf.f;
+        finalize_body<true>(f, sh);
+        if (fin_bad && threadIdx.x == 0 && f.tail) f.tail[2 + UMLH_S_LOSS_IMG] = __builtin_nanf("");
+        return;
+    }
+    // ---- update: sub-block `sub`, thread t of 256 ----
+    const int sub = 2 * (bid - nfwd - ndw) + ((int)threadIdx.x >> 8), t = (int)threadIdx.x & 255;
+    const long long n4 = (long long)hf.C * hf.K / 4;
+    const long long g4 = (long long)sub * 256 + t;
+    const bool live = sub < hf.n_sub && g4 < n4;
+    const long long i = (live ? g4 : 0) * 4;
+    f32x4v gi = {0.f, 0.f, 0.f, 0.f}, gt = gi, p0 = gi, m0 = gi, v0 = gi;
+    if (live) {
+        p0 = *reinterpret_cast<f32x4v*>(hf.p + i);
+        m0 = *reinterpret_cast<f32x4v*>(hf.m + i);
+        if (hf.o.kind != UMLH_OPT_SGD) v0 = *reinterpret_cast<f32x4v*>(hf.v + i);
+    }
+    __shared__ int upd_bad;
+    if (threadIdx.x == 0) upd_bad = 0;
+    __syncthreads();
+    if ((t >> 6) == 0 && sub < hf.n_sub) {                   // wave 0 of the sub-block: granules of its tile row(s)
+        const long long e0 = (long long)sub * 1024, e1 = min(e0 + 1023, (long long)hf.C * hf.K - 1);
+        const int m_lo = (int)(e0 / hf.K) / 128, m_hi = (int)(e1 / hf.K) / 128;
+        if (!sweep_granules(gate.publish, m_lo * hf.dw_per_row, (m_hi - m_lo + 1) * hf.dw_per_row, gate.epoch, t & 63, 64)) upd_bad = 1;
+    }
+    __syncthreads();
+    if (!live) return;
+    {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hf.slabs), 0,
+                                                                      (int)((size_t)hf.n_slabs * hf.slab_stride * 4), 0x00020000);
+        for (int sI = 0; sI < hf.n_slabs_img; ++sI)
+            gi += __builtin_bit_cast(f32x4v, load_coherent_b128(rs, (unsigned)(((size_t)sI * hf.slab_stride + i) * 4)));
+        for (int sI = hf.n_slabs_img; sI < hf.n_slabs; ++sI)
+            gt += __builtin_bit_cast(f32x4v, load_coherent_b128(rs, (unsigned)(((size_t)sI * hf.slab_stride + i) * 4)));
+    }
+    const f32x4v g0 = gi + gt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float pa = p0[j], mb = m0[j], vc = v0[j];
+        opt_update(hf.o, upd_bad ? __builtin_nanf("") : g0[j], pa, mb, vc);
+        p0[j] = pa; m0[j] = mb; v0[j] = vc;
+    }
+    store_out_f32x4(hf.p + i, p0, 0);
+    store_out_f32x4(hf.m + i, m0, 0);
+    if (hf.o.kind != UMLH_OPT_SGD) store_out_f32x4(hf.v + i, v0, 0);
+    if (hf.shadow != nullptr) {
+        const int cls = (int)(i / hf.K), k = (int)(i % hf.K);
+        const long long piece = ((long long)(k >> 4) * (hf.cpad / 32) + (cls >> 5)) * 64 + (cls & 31) + 32 * ((k >> 3) & 1);
+        typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+        const u32x2s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3])};
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(hf.shadow + piece * 8 + (k & 7)), "v"(w) : "memory");
     }
 }
 
@@ -1282,6 +1385,44 @@ int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, 
     return (int)hipGetLastError();
 }
 
+#define STEP_CASE(CT, W)                                                                                           \
+    if (ctw == CT && wc == W) {                                                                                    \
+        size_t sm = fwd_smem_bytes_b(CT, W, 1);                                                                    \
+        if (sm < (size_t)DW_LDS_BYTES) sm = DW_LDS_BYTES;                                                          \
+        static unsigned long long attr_done = 0;                                                                   \
+        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_bf16<CT, W>),                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);               \
+            if (e != hipSuccess) return (int)e;                                                                    \
+            attr_done |= 1ULL << (dev_ & 63);                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL((step_bf16<CT, W>), dim3(nfwd + ndw + nhead + 1), dim3(512), sm, stream, fa, ga, gate, flags, nfwd, ndw, h); \
+        return (int)hipGetLastError();                                                                             \
+    }
+
+// forward, dW and the update + finalize in one launch; flags: [nfwd] forward granules, then [ndw] dW granules
+int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
+                          unsigned epoch, int ts, int total_cols, const HeadFuse* hf, hipStream_t stream) {
+    if (nfwd <= 0 || g->M <= 0 || g->N <= 0 || !flags || epoch == 0 || !a->dzt || !hf) return (int)hipErrorInvalidValue;
+    if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
+    if (g->k_switch % DKT != 0 || g->bcs < 64 || g->N % 8 != 0 || umlh_plain_stores()) return (int)hipErrorInvalidValue;
+    if (hf->K % 8 != 0 || hf->C != g->M || hf->K != g->N || hf->slab_stride % 4 != 0) return (int)hipErrorInvalidValue;
+    const int nx = (g->N + DBN - 1) / DBN;
+    const int ndw = nx * ((g->M + DBM - 1) / DBM) * splits;
+    FwdArgsB fa = *a; fa.plain = 0;
+    DwArgsB ga = *g; ga.plain = 0;
+    HeadFuse h = *hf;
+    const long long n4 = (long long)h.C * h.K / 4;
+    h.n_sub = (int)((n4 + 255) / 256);
+    h.dw_per_row = nx * splits;
+    const int nhead = (h.n_sub + 1) / 2;
+    DwGate gate = {flags, epoch, ts, total_cols, flags + nfwd};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    STEP_CASE(1, 1) STEP_CASE(1, 2) STEP_CASE(1, 4) STEP_CASE(1, 8) STEP_CASE(2, 8) STEP_CASE(4, 8)
+    return (int)hipErrorInvalidValue;
+}
+
 #define FWD_DW_CASE(CT, W)                                                                                         \
     if (ctw == CT && wc == W) {                                                                                    \
         size_t sm = fwd_smem_bytes_b(CT, W, 1);                                                                    \
@@ -1306,7 +1447,7 @@ int umlh_bf16_launch_fwd_dw(const FwdArgsB* a, int ctw, int wc, int nfwd, const 
     const int ndw = ((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits;
     FwdArgsB fa = *a; fa.plain = 0;
     DwArgsB ga = *g; ga.plain = 0;
-    DwGate gate = {flags, epoch, ts, total_cols};
+    DwGate gate = {flags, epoch, ts, total_cols, nullptr};
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     FWD_DW_CASE(1, 1) FWD_DW_CASE(1, 2) FWD_DW_CASE(1, 4) FWD_DW_CASE(1, 8) FWD_DW_CASE(2, 8) FWD_DW_CASE(4, 8)

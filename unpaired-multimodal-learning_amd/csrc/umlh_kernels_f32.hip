@@ -931,51 +931,9 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(MultiOptArgs a, OptArgs 
 // --------------------------------------------------------------------------- //
 // per-step scalars + logit-scale parameters
 // --------------------------------------------------------------------------- //
-__device__ __forceinline__ void finalize_body(const FinalizeArgs& f, float (*sh)[256]) {
-    const int tid = threadIdx.x;
-    if (f.partials != nullptr) {
-        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int b = tid; b < f.nb0 + f.nb1; b += 256) {
-            const float* q = f.partials + (size_t)b * 4;
-            int o = b < f.nb0 ? 0 : 3;
-            s[o + 0] += q[0]; s[o + 1] += q[1]; s[o + 2] += q[2];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) sh[j][tid] = s[j];
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) sh[j][tid] += sh[j][tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            float* t = f.tail;
-            t[0] = sh[2][0] * f.w0 * f.inv_rows0;                    // d loss / d img_scale
-            t[1] = sh[5][0] * f.w1 * f.inv_rows1;                    // d loss / d txt_scale
-            float* sc = t + 2;
-            sc[UMLH_S_LOSS_IMG] = sh[0][0] * f.inv_rows0;
-            sc[UMLH_S_LOSS_TXT] = sh[3][0] * f.inv_rows1;
-            sc[UMLH_S_ACC_IMG] = sh[1][0] * f.inv_rows0;
-            sc[UMLH_S_ACC_TXT] = sh[4][0] * f.inv_rows1;
-            sc[UMLH_S_GSCALE_IMG] = t[0];
-            sc[UMLH_S_GSCALE_TXT] = t[1];
-            sc[UMLH_S_CORRECT] = sh[1][0] + sh[4][0];
-            sc[UMLH_S_LOSS_SUM] = sh[0][0] + sh[3][0];
-        }
-        __syncthreads();
-    }
-    if (tid < UMLH_N_CORE_SCALARS && f.scalars_out) f.scalars_out[tid] = f.tail[2 + tid];
-    if (tid < 2 && ((f.update_mask >> tid) & 1)) {
-        float p = f.scales[tid], m = f.m_scales[tid], v = f.v_scales[tid];
-        opt_update(f.opt, f.tail[tid], p, m, v);
-        f.scales[tid] = p; f.m_scales[tid] = m; f.v_scales[tid] = v;
-    }
-}
-
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
     __shared__ float sh[6][256];
-    finalize_body(f, sh);
+    finalize_body<false>(f, sh);
 }
 
 // --------------------------------------------------------------------------- //
@@ -985,11 +943,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs f) {
 // partials to the step's scalars + update the learnable logit scales.
 // --------------------------------------------------------------------------- //
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
-}
 
 // 4 consecutive elements per thread (twice the workgroups of an 8-element split: at C*d = 512 000 that is 500 workgroups
 // = 2 per CU instead of one 4-wave workgroup per CU, and the kernel is bound by bytes in flight, not by arithmetic).
@@ -998,7 +951,7 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
                                                         float* __restrict__ v, OptArgs o, unsigned short* __restrict__ shadow,
                                                         int cpad, FinalizeArgs f, float* __restrict__ grad_out, DiagArgs dg) {
     __shared__ float sh[6][256];
-    if (blockIdx.x == gridDim.x - 1) { finalize_body(f, sh); return; }
+    if (blockIdx.x == gridDim.x - 1) { finalize_body<false>(f, sh); return; }
     const long long g4 = (long long)blockIdx.x * 256 + threadIdx.x;      // group of 4 consecutive k of one class row
     const long long n4 = (long long)C * K / 4;
     const bool live = g4 < n4;
