@@ -31,7 +31,8 @@
  *   UMLH_F32_DW=0        fp32 dW through the generic GEMM instead of dw_f32
  *   UMLH_ENC_GRAPH=0 / UMLH_ENC_FORK=1   encoder plans: no HIP-graph replay / weight-gradient work on a forked branch
  *   UMLH_FORCE_DP=1      take the data-parallel split step (grad -> all-reduce -> update) with one rank
- *   UMLH_DBG_FWD / UMLH_DBG_DW / UMLH_DBG_MICRO   in-kernel cycle stamps (scripts/fwd_stamps.py, dw_stamps.py, micro_stamps.py)
+ *   UMLH_DBG_FWD / UMLH_DBG_DW / UMLH_DBG_MICRO / UMLH_DBG_STEP   in-kernel stamps (scripts/fwd_stamps.py, dw_stamps.py,
+ *                        micro_stamps.py, step_timeline.py)
  */
 #ifndef UMLH_H
 #define UMLH_H

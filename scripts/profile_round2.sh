@@ -52,4 +52,5 @@ UMLH_BF16_FWD2D=1 python bench.py --no-cpu-baseline --no-fp32-leg 2>/dev/null | 
 UMLH_WT=0 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $o/${tag}_bench_plain_stores.json
 UMLH_BF16_FUSE=0 python bench.py --no-cpu-baseline --no-fp32-leg 2>/dev/null | tail -1 > $o/${tag}_bench_two_launches.json
 UMLH_BF16_FUSE=1 python bench.py --no-cpu-baseline --no-fp32-leg 2>/dev/null | tail -1 > $o/${tag}_bench_fwd_dw_one_launch.json
+python scripts/step_timeline.py 2>/dev/null > $o/${tag}_step_timeline.txt
 tail -2 $o/${tag}_bench.json | cut -c1-600

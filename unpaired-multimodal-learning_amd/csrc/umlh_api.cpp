@@ -41,7 +41,7 @@ extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
 int umlh_bf16_launch_fwd_q(const FwdArgsB* a, int nq, int tiles, hipStream_t stream);
 int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
-                          unsigned epoch, int ts, int total_cols, const HeadFuse* hf, hipStream_t stream);
+                          unsigned epoch, int ts, int total_cols, const HeadFuse* hf, unsigned long long* timeline, hipStream_t stream);
 int umlh_bf16_launch_fwd_dw(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
                             unsigned epoch, int ts, int total_cols, hipStream_t stream);
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream);
@@ -206,6 +206,7 @@ struct umlh_handle_s {
     unsigned fwd_epoch;         // bf16 2-D forward: launch tag of the exchange granules
     unsigned fuse_epoch;        // single-launch forward + dW: launch tag of the forward blocks' granules
     int fuse;                   // forward and dW of a linear bf16 head as one launch (default; UMLH_BF16_FUSE=0: two launches)
+    int dbg_step;               // UMLH_DBG_STEP=1: step_bf16 writes a per-block timeline into the debug buffer
     const HeadFuse* pending_head;   // set by train_step_impl: the update may ride in the same launch (step_bf16)
     bool head_fused_done;       // forward_backward took it
     // state carried from umlh_grad_step to umlh_apply_update
@@ -320,6 +321,7 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->fwd_epoch = 0;
     h->fuse_epoch = 0;
     h->pending_head = nullptr; h->head_fused_done = false;
+    { const char* e = getenv("UMLH_DBG_STEP"); h->dbg_step = (e && atoi(e) == 1) ? 1 : 0; }
     { const char* e = getenv("UMLH_BF16_FUSE"); h->fuse = e ? atoi(e) : 2; }   // 2 (default): the whole step as one launch; 1: forward + dW as one; 0: separate launches
     h->last_rows_img = h->last_rows_txt = 0;
     h->global_rows_img = h->global_rows_txt = 0;
@@ -983,7 +985,9 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
                 hf.n_slabs = splits; hf.n_slabs_img = sp.n_img;
                 HIPCHK(umlh_bf16_launch_step(&fb, h->ctw, h->wc, nb0 + nb1, &g, splits,
                                              reinterpret_cast<unsigned long long*>(ws(h, L.fuse_flags)), h->fuse_epoch, TS,
-                                             (nb0 + nb1) * TS, &hf, st), "step_bf16");
+                                             (nb0 + nb1) * TS, &hf,
+                                             (h->dbg_step && 4LL * (nb0 + nb1 + ndw_blocks + L.n_head / 2048 + 4) <= 64LL * L.max_blocks)
+                                                 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr, st), "step_bf16");
                 h->head_fused_done = true;
             } else if (fused) {
                 if (++h->fuse_epoch == 0) h->fuse_epoch = 1;

@@ -903,7 +903,8 @@ __device__ __forceinline__ u32x4 load_coherent_b128(__amdgpu_buffer_rsrc_t rsrc,
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 1 << 4 /* sc1 */);
 }
 
-struct DwGate { const unsigned long long* flags; unsigned epoch; int ts, total_cols; unsigned long long* publish; };   // publish: this launch's dW granules (or NULL)
+struct DwGate { const unsigned long long* flags; unsigned epoch; int ts, total_cols; unsigned long long* publish;   // publish: this launch's dW granules (or NULL)
+                unsigned long long* timeline; int tl_base; };   // UMLH_DBG_STEP=1: [block][4] s_memrealtime stamps (100 MHz): start, gate open, end
 constexpr int DW_LDS_BYTES = 2 * DBM * RSA * 2 + 2 * DKT * RSF * 2 + DIDS * 4;   // two A tiles, two F tiles, the split's row ids
 
 template <int AM, int OM, bool GATED>
@@ -936,6 +937,7 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, c
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #define DSTAMP(i) do { if (g.stamps && lane == 0) g.stamps[((size_t)vbid * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     DSTAMP(0);
+    if (GATED && gate.timeline && tid == 0) gate.timeline[(size_t)(gate.tl_base + vbid) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
 
     struct Stage { u32x4 a[2]; u32x4 f[2]; };
     Stage st[DNS];
@@ -1062,6 +1064,7 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, c
             if (bad && lane == 0) gate_bad = 1;
         }
         __syncthreads();
+        if (gate.timeline && tid == 0) gate.timeline[(size_t)(gate.tl_base + vbid) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         if (gate_bad && tid == 0) g.out[(size_t)z * g.slab_stride] = __builtin_nanf("");
 #pragma unroll
         for (int d = 0; d < DNS; ++d) gloadA(st[d], min(d, lastc));
@@ -1161,6 +1164,7 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, c
             }
     }
     DSTAMP(7);
+    if (GATED && gate.timeline && tid == 0) gate.timeline[(size_t)(gate.tl_base + vbid) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     if (GATED && gate.publish != nullptr) {              // the update blocks of the same launch wait for this split's slab
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1172,7 +1176,7 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, c
 template <int AM, int OM>
 __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     __shared__ __attribute__((aligned(16))) unsigned char dw_lds[DW_LDS_BYTES];
-    DwGate none = {nullptr, 0u, 32, 0, nullptr};
+    DwGate none = {nullptr, 0u, 32, 0, nullptr, nullptr, 0};
     dw_bf16_body<AM, OM, false>(g, (int)blockIdx.x, none, dw_lds);
 }
 
@@ -1222,11 +1226,14 @@ template <int CTW, int WC>
 __global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate gate, unsigned long long* flags, int nfwd, int ndw, HeadFuse hf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     const int bid = (int)blockIdx.x;
+    unsigned long long* tl = gate.timeline ? gate.timeline + (size_t)bid * 4 : nullptr;
+    if (tl && threadIdx.x == 0 && (bid < nfwd || bid >= nfwd + ndw)) tl[0] = __builtin_amdgcn_s_memrealtime();
     if (bid < nfwd) {
         fwd_ce_bf16_body<CTW, WC, 1>(a, bid, smem_dyn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) fq_store_granule(flags + bid, gate.epoch, 1.f);
+        if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     if (bid < nfwd + ndw) {
@@ -1241,8 +1248,10 @@ __global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate g
         if (!sweep_granules(flags, 0, nfwd, gate.epoch, (int)threadIdx.x & 63, 64)) fin_bad = 1;   // every wave sweeps (cheap, one block)
         __syncthreads();
         FinalizeArgs f = hf.f;
+        if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
         finalize_body<true>(f, sh);
         if (fin_bad && threadIdx.x == 0 && f.tail) f.tail[2 + UMLH_S_LOSS_IMG] = __builtin_nanf("");
+        if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     // ---- update: sub-block `sub`, thread t of 256 ----
@@ -1266,6 +1275,7 @@ __global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate g
         if (!sweep_granules(gate.publish, m_lo * hf.dw_per_row, (m_hi - m_lo + 1) * hf.dw_per_row, gate.epoch, t & 63, 64)) upd_bad = 1;
     }
     __syncthreads();
+    if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
     if (!live) return;
     {
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hf.slabs), 0,
@@ -1292,6 +1302,7 @@ __global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate g
         const u32x2s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3])};
         asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(hf.shadow + piece * 8 + (k & 7)), "v"(w) : "memory");
     }
+    if (tl && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[2] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // --------------------------------------------------------------------------- //
@@ -1402,7 +1413,7 @@ int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, 
 
 // forward, dW and the update + finalize in one launch; flags: [nfwd] forward granules, then [ndw] dW granules
 int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
-                          unsigned epoch, int ts, int total_cols, const HeadFuse* hf, hipStream_t stream) {
+                          unsigned epoch, int ts, int total_cols, const HeadFuse* hf, unsigned long long* timeline, hipStream_t stream) {
     if (nfwd <= 0 || g->M <= 0 || g->N <= 0 || !flags || epoch == 0 || !a->dzt || !hf) return (int)hipErrorInvalidValue;
     if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
     if (g->k_switch % DKT != 0 || g->bcs < 64 || g->N % 8 != 0 || umlh_plain_stores()) return (int)hipErrorInvalidValue;
@@ -1416,7 +1427,7 @@ int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const Dw
     h.n_sub = (int)((n4 + 255) / 256);
     h.dw_per_row = nx * splits;
     const int nhead = (h.n_sub + 1) / 2;
-    DwGate gate = {flags, epoch, ts, total_cols, flags + nfwd};
+    DwGate gate = {flags, epoch, ts, total_cols, flags + nfwd, timeline, nfwd};
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     STEP_CASE(1, 1) STEP_CASE(1, 2) STEP_CASE(1, 4) STEP_CASE(1, 8) STEP_CASE(2, 8) STEP_CASE(4, 8)
@@ -1447,7 +1458,7 @@ int umlh_bf16_launch_fwd_dw(const FwdArgsB* a, int ctw, int wc, int nfwd, const 
     const int ndw = ((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits;
     FwdArgsB fa = *a; fa.plain = 0;
     DwArgsB ga = *g; ga.plain = 0;
-    DwGate gate = {flags, epoch, ts, total_cols, nullptr};
+    DwGate gate = {flags, epoch, ts, total_cols, nullptr, nullptr, 0};
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     FWD_DW_CASE(1, 1) FWD_DW_CASE(1, 2) FWD_DW_CASE(1, 4) FWD_DW_CASE(1, 8) FWD_DW_CASE(2, 8) FWD_DW_CASE(4, 8)
