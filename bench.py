@@ -221,10 +221,15 @@ def main():
             scheduler.step()
             return int(ii.numel()) + int(ti.numel())
 
-        def run_steps(n):
-            """Blocks of `--block` steps through ONE umlh_train_steps call each (the host prepares the next block's
-            index vectors while the GPU runs) -- with a communicator attached the same call also runs the
-            data-parallel step (grad -> ncclAllReduce -> update, all enqueued from C); otherwise N>1 steps from Python."""
+        ahead = {}          # block length -> index vectors drawn one block ahead (consumed in draw order)
+
+        def run_steps(n, next_n=None):
+            """Blocks of `--block` steps through ONE umlh_train_steps call each -- with a communicator attached the same
+            call also runs the data-parallel step (grad -> ncclAllReduce -> update, all enqueued from C); otherwise N>1
+            steps from Python.  The index vectors of the NEXT block are drawn right after a block is enqueued, i.e. while
+            the GPU runs it, as in an unfenced training loop (finetune.train() enqueues blocks back to back); `next_n` tells
+            the first block length of the following call.  Every timed block therefore still contains exactly one draw
+            (and its shuffle kernels on the stream); only the host latency in front of the first launch is hidden."""
             rows = 0
             if dp_path and not c_level_dp:
                 for _ in range(n):
@@ -233,17 +238,24 @@ def main():
             done = 0
             while done < n:
                 m = min(args.block, n - done)
-                bi, bt = _draw_block(img_src, txt_src, m)   # as finetune.train(): consecutive batches of an epoch as ONE index slice
+                blk = ahead.pop(m, None)
+                if blk is None:
+                    ahead.clear()                           # (a look-ahead of another length is dropped: the draws are never reordered)
+                    blk = _draw_block(img_src, txt_src, m)  # as finetune.train(): consecutive batches of an epoch as ONE index slice
+                bi, bt = blk
                 engine.train_steps(tab_i, bi, tab_t, bt, scheduler.lr_table(m), first_step=optimizer.step_count + 1,
                                    alpha=1.0, scalars_out=slot(m))
                 optimizer.step_count += m
                 scheduler.step(scheduler.last_epoch + m)
                 rows += sum(int(b[0].numel()) if isinstance(b, tuple) else int(b.numel()) for b in bi + bt)
                 done += m
+                m_next = min(args.block, n - done) if done < n else (min(args.block, next_n) if next_n else 0)
+                if m_next > 0:
+                    ahead[m_next] = _draw_block(img_src, txt_src, m_next)
             return rows
 
-        run_steps(prime)
-        run_steps(warmup)
+        run_steps(prime, warmup)
+        run_steps(warmup, steps)
         if watchdog is not None:
             fence()
             watchdog.cancel()
@@ -251,7 +263,7 @@ def main():
         for _ in range(repeats):
             fence()
             t0 = time.perf_counter()
-            rows = run_steps(steps)
+            rows = run_steps(steps, steps)
             t_enq = time.perf_counter() - t0
             fence()
             dt = time.perf_counter() - t0
@@ -362,7 +374,8 @@ def main():
                           "parallelism": f"dp{world}" + (" (REHEARSAL: ranks share GPUs, gloo all-reduce -- not a measurement)" if rehearsal else ""),
                           "dp_stepping": ("c-level rccl" if head["c_level_dp"] else "python per step") if dp_path else "single gpu",
                           "precision_mode": args.precision, "order_rng": args.order_rng, "steps_per_call": args.block,
-                          "timing": f"median of {repeats} blocks of {args.steps} steps after {args.prime}+{args.warmup} untimed steps"},
+                          "timing": f"median of {repeats} blocks of {args.steps} steps after {args.prime}+{args.warmup} untimed steps; "
+                                    "each block draws the next block's index vectors after enqueuing its own steps"},
                "block_ms_per_step": head["block_ms_per_step"],
                "final_loss": {"img": round(final[0], 4), "txt": round(final[1], 4)},
                "host_enqueue_ms_per_step": round(head["host_enqueue_ms_per_step"], 4),
