@@ -282,6 +282,36 @@ def test_bf16_single_launch_forward_dw_equals_two_launches_bit_for_bit(monkeypat
     assert torch.isfinite(out["2"][0]).all()
 
 
+@pytest.mark.parametrize("opt,learn", [("sgd", True), ("adam", False), ("adamw", True)])
+def test_bf16_single_launch_step_optimizers_and_learnable_temperature(opt, learn, monkeypatch):
+    """The one-launch step against the three-launch step for SGD-momentum / Adam / AdamW and with learnable logit scales
+    (their update rides in the finalize block): weights, moments and scales bit for bit after 12 steps."""
+    import umlh
+    rng = np.random.default_rng(21)
+    d, C, n = 256, 300, 3000
+    xi, yi, xt, yt, w = _case(rng, d, C, n, 2000, 20.0)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("UMLH_BF16_FUSE", mode)
+        e = umlh.HeadEngine(d, d, C, optimizer=opt, weight_decay=0.01, learnable_temp=learn, max_rows_img=512, max_rows_txt=512,
+                            precision="bf16", device=DEV)
+        e.w_head.copy_(torch.from_numpy(w)); e.scales.fill_(20.0)
+        bi_t, bt_t = _rb(xi, yi), _rb(xt, yt)
+        bi_t.feats_bf16, bt_t.feats_bf16 = umlh.to_bf16(bi_t.feats), umlh.to_bf16(bt_t.feats)
+        g = torch.Generator().manual_seed(4)
+        for k in range(12):
+            ii = torch.randint(0, n, (512 if k % 2 else 321,), generator=g).to(DEV)
+            ti = torch.randint(0, 2000, (384,), generator=g).to(DEV)
+            e.train_step(umlh.RowBatch(bi_t.feats, bi_t.labels, ii, feats_bf16=bi_t.feats_bf16),
+                         umlh.RowBatch(bt_t.feats, bt_t.labels, ti, feats_bf16=bt_t.feats_bf16), lr=1e-2, step=k + 1)
+        torch.cuda.synchronize()
+        out[mode] = (e.w_head.clone(), e.m_head.clone(), e.v_head.clone(), e.scales.clone())
+    for a, b in zip(out["0"], out["2"]):
+        assert torch.equal(a, b)
+    if learn:
+        assert float((out["2"][3] - 20.0).abs().max()) > 0.0      # the scales did move
+
+
 def test_bf16_two_layer_head_split_step_equals_fused_step():
     """Data-parallel split (grad_step -> apply_update) == fused train_step for the bf16 2-layer head: same weights,
     optimizer state and scalars after 3 steps (single rank: the all-reduce is the identity)."""
