@@ -12,7 +12,9 @@
  * Conventions
  *   - plain C types only; every pointer marked "device" is HIP device memory
  *     owned by the caller (torch allocates it); the library never allocates,
- *     frees or synchronises, so every call is graph-capturable.
+ *     frees or synchronises, so every call is graph-capturable (on a capturing stream the bf16 step takes its
+ *     launch-per-kernel form: the one-launch step tags its in-launch hand-offs with a per-launch argument; the
+ *     single-launch micro path and the opt-in 2-D forward use such tags too and are not meant for capture).
  *   - every function returns 0 on success or a negative UMLH_E_* code;
  *     umlh_last_error() returns a thread-local message for the last failure.
  *   - all work is enqueued on the hipStream_t passed as `void* stream`

@@ -312,6 +312,40 @@ def test_bf16_single_launch_step_optimizers_and_learnable_temperature(opt, learn
         assert float((out["2"][3] - 20.0).abs().max()) > 0.0      # the scales did move
 
 
+def test_bf16_train_step_captured_in_a_graph_replays_correctly():
+    """A bf16 train step captured into a HIP graph (torch.cuda.graph) and replayed equals the same step run eagerly the same
+    number of times: on a capturing stream the engine takes the launch-per-kernel form (the one-launch step's hand-off tags are
+    launch arguments and would be stale in a replay)."""
+    import umlh
+    rng = np.random.default_rng(8)
+    d, C, n = 256, 300, 2000
+    xi, yi, xt, yt, w = _case(rng, d, C, n, 1500, 20.0)
+    ii = torch.as_tensor(rng.permutation(n)[:512]).to(DEV)
+    ti = torch.as_tensor(rng.permutation(1500)[:384]).to(DEV)
+
+    def make():
+        e = _engine(w.copy(), 20.0, 512, 512, "bf16")
+        bi_t, bt_t = _rb(xi, yi), _rb(xt, yt)
+        bi_t.feats_bf16, bt_t.feats_bf16 = umlh.to_bf16(bi_t.feats), umlh.to_bf16(bt_t.feats)
+        bi = umlh.RowBatch(bi_t.feats, bi_t.labels, ii, feats_bf16=bi_t.feats_bf16)
+        bt = umlh.RowBatch(bt_t.feats, bt_t.labels, ti, feats_bf16=bt_t.feats_bf16)
+        return e, bi, bt
+    e1, bi, bt = make()
+    for _ in range(4):
+        e1.train_step(bi, bt, lr=1e-2, step=3)
+    torch.cuda.synchronize()
+    e2, bi2, bt2 = make()
+    e2.train_step(bi2, bt2, lr=1e-2, step=3)                # eager once (also warms every lazily set attribute)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        e2.train_step(bi2, bt2, lr=1e-2, step=3)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(e1.w_head, e2.w_head) and torch.equal(e1.m_head, e2.m_head) and torch.equal(e1.v_head, e2.v_head)
+
+
 def test_bf16_two_layer_head_split_step_equals_fused_step():
     """Data-parallel split (grad_step -> apply_update) == fused train_step for the bf16 2-layer head: same weights,
     optimizer state and scalars after 3 steps (single rank: the all-reduce is the identity)."""

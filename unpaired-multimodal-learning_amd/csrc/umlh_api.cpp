@@ -952,7 +952,11 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         }
         // forward + dW as one launch (linear head, 1-D forward, write-through stores).  In profiling mode the interval
         // mark 1 -> 2 is then empty and mark 2 -> 3 holds the one launch.
-        const bool fused = h->fuse && want_grad && !proj && !L.fwd_nq && h->stw == 1 && L.fuse_flags &&
+        // (not while the stream is being captured into a HIP graph: the granules' epoch tag is a launch argument, a replay
+        // would find the previous replay's tags and pass its gates early)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = h->fuse && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        const bool fused = h->fuse && !capturing && want_grad && !proj && !L.fwd_nq && h->stw == 1 && L.fuse_flags &&
                            !umlh_plain_stores() && fb.dbg == 0 && h->dbg_dw == 0;
         if (!L.fwd_nq && !fused)
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
