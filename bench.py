@@ -226,7 +226,7 @@ def main():
         def run_steps(n, next_n=None):
             """Blocks of `--block` steps through ONE umlh_train_steps call each -- with a communicator attached the same
             call also runs the data-parallel step (grad -> ncclAllReduce -> update, all enqueued from C); otherwise N>1
-            steps from Python.  The index vectors of the NEXT block are drawn right after a block is enqueued, i.e. while
+            steps from Python.  The index vectors of the NEXT block are drawn (and its call marshalled) right after a block is enqueued, i.e. while
             the GPU runs it, as in an unfenced training loop (finetune.train() enqueues blocks back to back); `next_n` tells
             the first block length of the following call.  Every timed block therefore still contains exactly one draw
             (and its shuffle kernels on the stream); only the host latency in front of the first launch is hidden."""
@@ -241,17 +241,18 @@ def main():
                 blk = ahead.pop(m, None)
                 if blk is None:
                     ahead.clear()                           # (a look-ahead of another length is dropped: the draws are never reordered)
-                    blk = _draw_block(img_src, txt_src, m)  # as finetune.train(): consecutive batches of an epoch as ONE index slice
-                bi, bt = blk
-                engine.train_steps(tab_i, bi, tab_t, bt, scheduler.lr_table(m), first_step=optimizer.step_count + 1,
-                                   alpha=1.0, scalars_out=slot(m))
+                    bi, bt = _draw_block(img_src, txt_src, m)   # as finetune.train(): consecutive batches of an epoch as ONE index slice
+                    blk = (bi, bt, engine.prepare_steps(tab_i, bi, tab_t, bt, scheduler.lr_table(m)))
+                bi, bt, prep = blk
+                engine.train_steps_prepared(prep, first_step=optimizer.step_count + 1, alpha=1.0, scalars_out=slot(m))
                 optimizer.step_count += m
                 scheduler.step(scheduler.last_epoch + m)
                 rows += sum(int(b[0].numel()) if isinstance(b, tuple) else int(b.numel()) for b in bi + bt)
                 done += m
                 m_next = min(args.block, n - done) if done < n else (min(args.block, next_n) if next_n else 0)
-                if m_next > 0:
-                    ahead[m_next] = _draw_block(img_src, txt_src, m_next)
+                if m_next > 0:                              # (the scheduler already stands at the next block's first step)
+                    nbi, nbt = _draw_block(img_src, txt_src, m_next)
+                    ahead[m_next] = (nbi, nbt, engine.prepare_steps(tab_i, nbi, tab_t, nbt, scheduler.lr_table(m_next)))
             return rows
 
         run_steps(prime, warmup)
@@ -375,7 +376,7 @@ def main():
                           "dp_stepping": ("c-level rccl" if head["c_level_dp"] else "python per step") if dp_path else "single gpu",
                           "precision_mode": args.precision, "order_rng": args.order_rng, "steps_per_call": args.block,
                           "timing": f"median of {repeats} blocks of {args.steps} steps after {args.prime}+{args.warmup} untimed steps; "
-                                    "each block draws the next block's index vectors after enqueuing its own steps"},
+                                    "each block draws and marshals the next block's index vectors after enqueuing its own steps"},
                "block_ms_per_step": head["block_ms_per_step"],
                "final_loss": {"img": round(final[0], 4), "txt": round(final[1], 4)},
                "host_enqueue_ms_per_step": round(head["host_enqueue_ms_per_step"], 4),

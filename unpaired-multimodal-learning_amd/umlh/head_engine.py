@@ -291,10 +291,22 @@ class HeadEngine:
         ``*_table`` = (feats, labels[, feats_bf16]) device tensors or None; ``*_index_batches``
         = one int64 device index vector per step, or (index slice, [batch sizes]) entries that each cover
         several consecutive steps."""
+        self.train_steps_prepared(self.prepare_steps(img_table, img_index_batches, txt_table, txt_index_batches, lrs),
+                                  first_step, alpha=alpha, img_alpha=img_alpha, scalars_out=scalars_out)
+
+    def prepare_steps(self, img_table, img_index_batches, txt_table, txt_index_batches, lrs):
+        """The host-side half of ``train_steps`` (argument checks, offsets, the concatenated index vector, ctypes arrays) done
+        ahead of time -- e.g. for the NEXT block while the GPU still runs the current one; pass the result to
+        ``train_steps_prepared``.  The learning rates are the ones of the steps the block will run."""
         n = len(lrs)
         si, keep_i = self._make_stream(img_table, img_index_batches, self.d_img, self.cfg.max_rows_img, n)
         st, keep_t = self._make_stream(txt_table, txt_index_batches, self.d_shared, self.cfg.max_rows_txt, n)
         lr_arr = (C.c_double * n)(*[float(x) for x in lrs])
+        return (n, si, st, lr_arr, keep_i, keep_t)
+
+    def train_steps_prepared(self, prep, first_step: int, alpha: float = 1.0, img_alpha: float = 1.0,
+                             scalars_out: Optional[torch.Tensor] = None) -> None:
+        n, si, st, lr_arr, keep_i, keep_t = prep
         lock = ENQUEUE_LOCK
         if lock is not None:
             lock.acquire()
