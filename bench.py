@@ -297,11 +297,12 @@ def main():
         if fused:
             # UMLH_BF16_FUSE: 2 (default) = the update and the step scalars ride in the same launch too (single-GPU step only:
             # the data-parallel split step keeps the update behind the all-reduce); 1 = forward + dW
-            whole = os.environ.get("UMLH_BF16_FUSE", "2") not in ("0", "1") and not dp_path
-            name = "step" if whole else "fwd_dw"
+            whole = os.environ.get("UMLH_BF16_FUSE", "2") not in ("0", "1")
+            # data-parallel split step: the same launch ends with the slab sum into the gradient message (no update)
+            name = ("step_grad" if dp_path else "step") if whole else "fwd_dw"
             acc[name] = acc.pop("dw_head")
             acc["empty_interval_fwd"] = acc.pop("fwd_ce")
-            if whole:
+            if whole and not dp_path:
                 acc["empty_interval_update"] = acc.pop("reduce_update")
             flops = {name: 2 * 2.0 * 2 * BATCH * C * D}
         dom = max(flops, key=lambda n: acc[n])
@@ -318,7 +319,7 @@ def main():
             roof["empty_interval_ms"] = round(acc["proj_bwd"], 4)
         if precision == "bf16":
             pmc, src = latest_pmc()
-            key = {"fwd_ce": "fwd_ce_bf16", "dw_head": "dw_bf16", "fwd_dw": "fwd_dw_bf16", "step": "step_bf16"}[dom]
+            key = {"fwd_ce": "fwd_ce_bf16", "dw_head": "dw_bf16", "fwd_dw": "fwd_dw_bf16", "step": "step_bf16", "step_grad": "step_bf16"}[dom]
             if pmc and key in pmc:
                 roof["traffic"] = pmc[key].get("hbm_bytes_corrected")
                 roof["traffic_source"] = f"static: {src} (rocprofv3 --pmc passes, not collected in this run)"

@@ -1664,10 +1664,24 @@ static int grad_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_b
     const bool overlap = comm && h->cfg.has_proj && h->comm_stream != nullptr && (img ? img->rows : 0) > 0;
     h->overlap_pending = overlap;
     h->overlap_hy = hy; h->overlap_img = img; h->overlap_txt = txt;
+    // linear bf16 head: the slab sum into the message (and the step scalars) rides in the forward + dW launch
+    HeadFuse hfuse;
+    memset(&hfuse, 0, sizeof(hfuse));
+    h->head_fused_done = false;
+    h->pending_head = nullptr;
+    if (h->cfg.precision == UMLH_PREC_BF16 && !h->cfg.has_proj && h->cfg.d_shared % 8 == 0 && !h->dp_diag && !overlap) {
+        hfuse.slabs = ws(h, h->L.slabs_head); hfuse.slab_stride = h->L.n_head; hfuse.C = h->cfg.num_classes; hfuse.K = h->cfg.d_shared;
+        hfuse.grad_out = grads; hfuse.cpad = 32 * h->ctw * h->wc;
+        hfuse.o = make_opt(h->cfg, *hy); hfuse.f = make_finalize(h, img, txt, hy, true, nullptr, false);
+        h->pending_head = &hfuse;
+    }
     int rc = forward_backward(h, img, txt, hy, true, st, &sh, &sp);
+    h->pending_head = nullptr;
     h->overlap_pending = false;
     if (rc) return rc;
-    if (!overlap) { rc = dp_reduce_head(h, img, txt, hy, sh, st); if (rc) return rc; }
+    const bool head_done = h->head_fused_done;
+    h->head_fused_done = false;
+    if (!overlap && !head_done) { rc = dp_reduce_head(h, img, txt, hy, sh, st); if (rc) return rc; }
     OptArgs o = make_opt(h->cfg, *hy);
     if (h->cfg.has_proj) {
         float* gp = grads + msg_head_len(h);

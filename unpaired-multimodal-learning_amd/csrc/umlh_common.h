@@ -297,6 +297,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 struct HeadFuse {
     const float* slabs; int n_slabs, n_slabs_img; long long slab_stride; int C, K;
     float* p; float* m; float* v; unsigned short* shadow; int cpad;
+    float* grad_out;             // data-parallel split step: the summed gradient goes here and nothing is updated (p, m, v, shadow unused)
     int n_sub;                   // 256-thread sub-blocks of the update (two per workgroup)
     int dw_per_row;              // dW blocks per 128-class tile row (column tiles x K splits): the granules a sub-block waits for
     OptArgs o; FinalizeArgs f;

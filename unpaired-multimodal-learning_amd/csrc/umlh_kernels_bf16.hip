@@ -1261,7 +1261,8 @@ __global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate g
     const bool live = sub < hf.n_sub && g4 < n4;
     const long long i = (live ? g4 : 0) * 4;
     f32x4v gi = {0.f, 0.f, 0.f, 0.f}, gt = gi, p0 = gi, m0 = gi, v0 = gi;
-    if (live) {
+    const bool upd = hf.grad_out == nullptr;                 // (grid-uniform) else: the data-parallel split step's gradient only
+    if (live && upd) {
         p0 = *reinterpret_cast<f32x4v*>(hf.p + i);
         m0 = *reinterpret_cast<f32x4v*>(hf.m + i);
         if (hf.o.kind != UMLH_OPT_SGD) v0 = *reinterpret_cast<f32x4v*>(hf.v + i);
@@ -1286,6 +1287,12 @@ __global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate g
             gt += __builtin_bit_cast(f32x4v, load_coherent_b128(rs, (unsigned)(((size_t)sI * hf.slab_stride + i) * 4)));
     }
     const f32x4v g0 = gi + gt;
+    if (!upd) {
+        const float nanv = __builtin_nanf("");
+        store_out_f32x4(hf.grad_out + i, upd_bad ? f32x4v{nanv, nanv, nanv, nanv} : g0, 0);
+        if (tl && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[2] = __builtin_amdgcn_s_memrealtime(); }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float pa = p0[j], mb = m0[j], vc = v0[j];
