@@ -956,7 +956,10 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
         // would find the previous replay's tags and pass its gates early)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         const bool capturing = h->fuse && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-        const bool fused = h->fuse && !capturing && want_grad && !proj && !L.fwd_nq && h->stw == 1 && L.fuse_flags &&
+        // (the coherent loads address dZ^T and the slabs through 32-bit buffer offsets)
+        const bool fits32 = (unsigned long long)((r0p + r1p + 63) / 64) * crows * 128ull < (1ull << 31) &&
+                            (unsigned long long)L.scap_head * L.n_head * 4ull < (1ull << 31);
+        const bool fused = h->fuse && !capturing && fits32 && want_grad && !proj && !L.fwd_nq && h->stw == 1 && L.fuse_flags &&
                            !umlh_plain_stores() && fb.dbg == 0 && h->dbg_dw == 0;
         if (!L.fwd_nq && !fused)
         HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
