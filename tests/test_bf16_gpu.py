@@ -346,6 +346,46 @@ def test_bf16_train_step_captured_in_a_graph_replays_correctly():
     assert torch.equal(e1.w_head, e2.w_head) and torch.equal(e1.m_head, e2.m_head) and torch.equal(e1.v_head, e2.v_head)
 
 
+_WT_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import umlh
+rng = np.random.default_rng(5)
+d, C, n = 256, 300, 2000
+x = rng.standard_normal((n, d)).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+y = rng.integers(0, C, n)
+w = rng.standard_normal((C, d)).astype(np.float32); w /= np.linalg.norm(w, axis=1, keepdims=True)
+out = []
+for prec in ("bf16", "fp32"):
+    e = umlh.HeadEngine(d, d, C, optimizer="adamw", weight_decay=0.01, max_rows_img=512, max_rows_txt=512, precision=prec, device="cuda:0")
+    e.w_head.copy_(torch.from_numpy(w)); e.scales.fill_(30.0)
+    X = torch.from_numpy(x).cuda(); Y = torch.from_numpy(y).cuda(); X16 = umlh.to_bf16(X)
+    g = torch.Generator().manual_seed(2)
+    for k in range(6):
+        ii = torch.randint(0, n, (512,), generator=g).cuda(); ti = torch.randint(0, n, (300,), generator=g).cuda()
+        e.train_step(umlh.RowBatch(X, Y, ii, feats_bf16=X16), umlh.RowBatch(X, Y, ti, feats_bf16=X16), lr=1e-2, step=k + 1)
+    torch.cuda.synchronize()
+    out.append(hashlib.sha256(e.w_head.cpu().numpy().tobytes() + e.v_head.cpu().numpy().tobytes()).hexdigest())
+print("DIGEST", *out)
+"""
+
+
+def test_plain_stores_switch_gives_identical_results(tmp_path):
+    """UMLH_WT=0 (plain instead of write-through stores, launch-per-kernel step) is read once per process: two child processes,
+    one per setting, must end six steps (bf16 and fp32) with bit-identical weights and second moments."""
+    import os, subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unpaired-multimodal-learning_amd")
+    script = tmp_path / "wt_case.py"
+    script.write_text(_WT_SCRIPT)
+    digests = {}
+    for wt in ("1", "0"):
+        env = dict(os.environ, UMLH_WT=wt)
+        r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[wt] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1]
+    assert digests["1"] == digests["0"]
+
+
 def test_bf16_two_layer_head_split_step_equals_fused_step():
     """Data-parallel split (grad_step -> apply_update) == fused train_step for the bf16 2-layer head: same weights,
     optimizer state and scalars after 3 steps (single rank: the all-reduce is the identity)."""
