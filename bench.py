@@ -25,6 +25,7 @@ import argparse
 import contextlib
 import glob
 import json
+import math
 import os
 import socket
 import statistics
@@ -280,6 +281,19 @@ def main():
         med = order[(repeats - 1) // 2]                 # the median block itself (lower median: a measured block)
         dt, rows = blocks[med]
         final = scal[cursor["k"] - 1].cpu().tolist()
+        # health gate BEFORE any number is reported (two N=2 rehearsals printed NaN losses and 100 ms blocks and
+        # exited 0): a bounded in-launch wait that gave up, a non-finite step scalar anywhere in the ring, or a timed block
+        # far off the median ends the run with a non-zero exit code and no JSON line
+        engine.check_status()
+        ring_used = scal[:max(cursor["k"], 1), :4]
+        if not bool(torch.isfinite(ring_used).all()) or not all(math.isfinite(v) for v in final[:4]):
+            raise SystemExit(f"[rank {rank}] bench: non-finite step scalars ({precision}; final loss img/txt = {final[0]}, {final[1]}): "
+                             "the run is invalid, no result line is printed")
+        slow = [b[0] for b in blocks if b[0] > 20.0 * dt]
+        if slow:
+            raise SystemExit(f"[rank {rank}] bench: {len(slow)} of {repeats} timed blocks took more than 20x the median block "
+                             f"({max(slow) / steps * 1e3:.3f} vs {dt / steps * 1e3:.4f} ms/step): stalled waits or a starved device; "
+                             "the run is invalid, no result line is printed")
         # roofline leg: per-kernel device time from HIP events recorded on the step's stream (RAW intervals: each
         # carries the cost of its two marker packets, so they read a few hundred ns above rocprofv3's kernel trace)
         engine.profile(True)

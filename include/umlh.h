@@ -230,6 +230,15 @@ int  umlh_micro_status(umlh_handle_t h, int32_t* status_out);
 /* number of persistent micro-step launches this handle has taken part in (which path ran: tests, logging) */
 int  umlh_micro_launches(umlh_handle_t h, int64_t* out);
 
+/* The one-launch step of a linear bf16 head (forward, dW, update as claimed tasks of ONE launch: finetune.py:180-195 without a
+ * kernel boundary).  Its in-launch waits are bounded (50 ms).  A wait that gives up (the device is being starved by another
+ * tenant, or a fault) sets a device status word; the step that hit it and every later step of the handle apply NO update from
+ * that point (a gradient that timed out is never stepped) and umlh_step_status returns, in status_out[0..3], {code (0 = ok),
+ * first task of the range waited on, launch tag, phase}.  It synchronises with the device.  The host mirror raises UmlhError
+ * whenever it reads the step scalars and finds the code set.  umlh_step_launches: one-launch steps taken by this handle. */
+int  umlh_step_status(umlh_handle_t h, int32_t* status_out);
+int  umlh_step_launches(umlh_handle_t h, int64_t* out);
+
 /* Data-parallel split of the step: gradients only, laid out as ONE flat fp32
  * buffer [g_head | g_proj | g_scales(2) | scalars(UMLH_N_SCALARS)] inside the
  * workspace, already divided by batch->global_rows so a SUM all-reduce over ranks

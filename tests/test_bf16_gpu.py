@@ -420,3 +420,120 @@ def test_bf16_two_layer_head_split_step_equals_fused_step():
     for name in ("w_head", "w_proj", "m_head", "v_head", "m_proj", "v_proj", "scales"):
         a, b = getattr(engines[0], name).cpu().numpy(), getattr(engines[1], name).cpu().numpy()
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=name)
+
+
+# ------------------------------------------------------------------------------------------------------------------- #
+# round 3: the one-launch step runs CLAIMED TASKS on persistent workgroups (csrc/umlh_common.h, StepCtl): no wait may depend on
+# dispatch order, on the width of the grid or on every workgroup being resident
+# ------------------------------------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("variant", ["grid24", "grid7", "lazy", "lazy_grid24", "grid24_dp"])
+def test_bf16_one_launch_step_is_independent_of_grid_width_and_of_who_runs_a_task(variant, monkeypatch):
+    """The step with (i) far fewer workgroups than tasks (every workgroup then walks several home tasks per phase through the
+    cold path), (ii) every fourth workgroup leaving its forward and dW home tasks alone, as if it had not been dispatched yet
+    (UMLH_STEP_LAZY: whoever needs a tile finds it untaken, takes it and runs it first -- update -> dW -> forward, the full
+    depth of tasks_wait's hand-back), and both together, ends 24 AdamW steps on changing batches with weights, moments and step
+    scalars BIT-identical to the launch-per-kernel step; the status word stays 0.  "_dp": the same for the data-parallel split
+    step (gradient message written by the update tasks, update as its own launch)."""
+    import umlh
+    rng = np.random.default_rng(33)
+    d, C, n = 512, 1000, 6000
+    xi, yi, xt, yt, w = _case(rng, d, C, n, 3000, 100.0)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("UMLH_BF16_FUSE", mode)
+        monkeypatch.delenv("UMLH_STEP_GRID", raising=False)
+        monkeypatch.delenv("UMLH_STEP_LAZY", raising=False)
+        monkeypatch.delenv("UMLH_FORCE_DP", raising=False)
+        if mode == "2":
+            if "grid24" in variant: monkeypatch.setenv("UMLH_STEP_GRID", "24")
+            if "grid7" in variant: monkeypatch.setenv("UMLH_STEP_GRID", "7")
+            if "lazy" in variant: monkeypatch.setenv("UMLH_STEP_LAZY", "1")
+        e = _engine(w.copy(), 100.0, 1024, 1024, "bf16")
+        bi_t, bt_t = _rb(xi, yi), _rb(xt, yt)
+        bi_t.feats_bf16, bt_t.feats_bf16 = umlh.to_bf16(bi_t.feats), umlh.to_bf16(bt_t.feats)
+        g = torch.Generator().manual_seed(19)
+        scal = torch.zeros(24, umlh.N_SCALARS, device=DEV)
+        for k in range(24):
+            ii = torch.randint(0, n, (1024 if k % 3 else 700,), generator=g).to(DEV)
+            ti = torch.randint(0, 3000, (1024 if k % 4 else 333,), generator=g).to(DEV)
+            bi = umlh.RowBatch(bi_t.feats, bi_t.labels, ii, feats_bf16=bi_t.feats_bf16) if k % 10 != 5 else None
+            bt = umlh.RowBatch(bt_t.feats, bt_t.labels, ti, feats_bf16=bt_t.feats_bf16) if k % 10 != 7 else None
+            if variant.endswith("_dp"):
+                e.grad_step(bi, bt, weights_unchanged=k > 0)
+                e.apply_update(lr=1e-3, step=k + 1, scalars_out=scal[k])
+            else:
+                e.train_step(bi, bt, lr=1e-3, step=k + 1, scalars_out=scal[k])
+        torch.cuda.synchronize()
+        assert e.step_status() == (0, 0, 0, 0)
+        assert (e.step_launches() > 0) == (mode == "2")
+        out[mode] = (e.w_head.clone(), e.m_head.clone(), e.v_head.clone(), scal.clone())
+    for a, b in zip(out["0"], out["2"]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(out["2"][0]).all() and torch.isfinite(out["2"][3][:, :4]).all()
+
+
+_SHARED_GPU_SCRIPT = r"""
+import sys, time, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import umlh
+steps, tag = int(sys.argv[2]), sys.argv[3]
+d, C, n_i, n_t, B = 512, 1000, 65536, 29940, 4096
+gen = torch.Generator(device="cuda").manual_seed(5)
+def rows(n):
+    x = torch.randn(n, d, generator=gen, device="cuda"); x /= x.norm(dim=1, keepdim=True)
+    return x, torch.randint(0, C, (n,), generator=gen, device="cuda")
+xi, yi = rows(n_i); xt, yt = rows(n_t)
+w = torch.randn(C, d, generator=gen, device="cuda"); w /= w.norm(dim=1, keepdim=True)
+e = umlh.HeadEngine(d, d, C, optimizer="adamw", weight_decay=0.01, max_rows_img=B, max_rows_txt=B, precision="bf16", device="cuda:0")
+e.w_head.copy_(w); e.scales.fill_(100.0)
+ti_tab, tt_tab = (xi, yi, umlh.to_bf16(xi)), (xt, yt, umlh.to_bf16(xt))
+g = torch.Generator().manual_seed(11)
+scal = torch.zeros(steps, umlh.N_SCALARS, device="cuda")
+blk = 20
+if tag != "solo":                 # rendezvous: both children are past their set-up before either starts stepping
+    import os
+    open(sys.argv[4] + "." + tag, "w").close()
+    t0 = time.time()
+    while not all(os.path.exists(sys.argv[4] + "." + t) for t in ("a", "b")) and time.time() - t0 < 120: time.sleep(0.01)
+worst = 0.0
+for k0 in range(0, steps, blk):
+    ib = [torch.randint(0, n_i, (B,), generator=g).cuda() for _ in range(blk)]
+    tb = [torch.randint(0, n_t, (B,), generator=g).cuda() for _ in range(blk)]
+    torch.cuda.synchronize(); t1 = time.time()
+    e.train_steps(ti_tab, ib, tt_tab, tb, [1e-3] * blk, first_step=k0 + 1, scalars_out=scal[k0:k0 + blk])
+    torch.cuda.synchronize(); worst = max(worst, (time.time() - t1) / blk)
+e.check_status()
+assert e.step_launches() == steps, e.step_launches()
+s = scal.cpu().numpy()
+print("RESULT", hashlib.sha256(e.w_head.cpu().numpy().tobytes() + s.tobytes()).hexdigest(), bool(np.isfinite(s[:, :4]).all()),
+      float(s[-1, 0]), "%.3f" % (worst * 1e3))
+"""
+
+
+def test_bf16_two_processes_step_cfg2_size_engines_concurrently_on_one_gpu(tmp_path):
+    """two processes driving cfg2-size bf16 engines (d = 512, C = 1000, 4096 + 4096 rows per step, the
+    one-launch step) at the same time on cuda:0.  With round 2's waits on lower block ids this timed out (2 s per wait) and
+    ended in NaN; claimed tasks do not care who holds the CUs: both children end 120 steps with finite losses, status 0 and
+    weights + per-step scalars bit-identical to a solo run of the same script, and no block of 20 steps comes near a wait's
+    50 ms bound per step."""
+    import os, subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unpaired-multimodal-learning_amd")
+    script = tmp_path / "shared_gpu_case.py"
+    script.write_text(_SHARED_GPU_SCRIPT)
+    rv = str(tmp_path / "rendezvous")
+    def parse(r):
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        f = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+        return f[1], f[2] == "True", float(f[3]), float(f[4])
+    solo = parse(subprocess.run([sys.executable, str(script), root, "120", "solo", rv], capture_output=True, text=True, timeout=600))
+    procs = [subprocess.Popen([sys.executable, str(script), root, "120", t, rv], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for t in ("a", "b")]
+    res = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        res.append(parse(subprocess.CompletedProcess(p.args, p.returncode, o, e)))
+    assert solo[1] and np.isfinite(solo[2])
+    for r in res:
+        assert r[1] and np.isfinite(r[2])
+        assert r[0] == solo[0]                   # same bits as the run that had the GPU to itself
+        assert r[3] < 5.0, r                     # ms per step of the slowest 20-step block (solo: ~0.05; a timed-out wait: >= 2.5)

@@ -40,10 +40,10 @@ int umlh_launch_iota(long long* dst, long long n, hipStream_t stream);
 extern "C" {
 int umlh_bf16_launch_fwd(const FwdArgsB* a, int ctw, int wc, int stw, int grid, hipStream_t stream);
 int umlh_bf16_launch_fwd_q(const FwdArgsB* a, int nq, int tiles, hipStream_t stream);
-int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
-                          unsigned epoch, int ts, int total_cols, const HeadFuse* hf, unsigned long long* timeline, hipStream_t stream);
-int umlh_bf16_launch_fwd_dw(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
-                            unsigned epoch, int ts, int total_cols, hipStream_t stream);
+int umlh_bf16_step_tasks(int nfwd, int M, int N, int splits, long long n_head, int with_head);
+int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned* claim,
+                          unsigned long long* done, unsigned* status, unsigned epoch, int ts, int total_cols, const HeadFuse* hf,
+                          unsigned long long* timeline, int cus, int lazy, hipStream_t stream);
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream);
 int umlh_enc_launch_bias_act(float* y, const float* b, long long M, int N, int relu, hipStream_t st);
 int umlh_enc_launch_relu_bwd(const float* y, float* dy, long long n, hipStream_t st);
@@ -65,6 +65,7 @@ int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, 
 }
 
 static thread_local char g_err[512] = "";
+static int device_cus(int dev);
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -78,6 +79,7 @@ static inline long long round_up(long long x, long long m) { return (x + m - 1) 
 
 struct Layout {                 // workspace partition, in floats from the base
     long long dzt, h, dht, slabs_head, slabs_proj, partials, diag_part, grads, w16, iota, zeros, dbg, wpt16, wht16, xch, fuse_flags, total;
+    long long ctl_tasks;        // one-launch step: task capacity of the control region at fuse_flags: [cap] u64 done, [cap] u32 claim, [16] u32 status
     int fwd_nq;                 // bf16 2-D forward (fwd_ce_bf16_q): class groups per row tile, 0 = the 1-D kernel
     long long mc_flags, mc_xchg, mc_ext, mc_tab, mc_desc;   // micro-step region (umlh_kernels_micro.hip); mc_flags = 0: unsupported shape
     int mc_nwg, mc_nch, mc_cw;
@@ -178,8 +180,9 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
             L.xch = take(2LL * (L.ldz / 128 + 2) * nq * 4 * 128);      // 8-byte granules
         }
     }
-    // single-launch forward + dW (fwd_dw_bf16): one granule per forward block
-    L.fuse_flags = c.precision == UMLH_PREC_BF16 && !c.has_proj ? take(2LL * (L.max_blocks + 8 + 4096)) : 0;   // forward blocks, then dW blocks
+    // one-launch step (step_bf16): per task one done granule (u64) and one claim word (u32), then the status words
+    L.ctl_tasks = L.max_blocks + 4096 + L.n_head / 2048 + 8;
+    L.fuse_flags = c.precision == UMLH_PREC_BF16 && !c.has_proj ? take(3LL * L.ctl_tasks + 16) : 0;
     // micro-step path: linear head whose width has a supported chunking (bf16 operand mode: widths that are multiples of 128)
     L.mc_flags = L.mc_xchg = L.mc_ext = L.mc_tab = L.mc_desc = 0;
     L.mc_nwg = (c.num_classes + UMLH_MICRO_CS - 1) / UMLH_MICRO_CS;
@@ -206,7 +209,10 @@ struct umlh_handle_s {
     unsigned fwd_epoch;         // bf16 2-D forward: launch tag of the exchange granules
     unsigned fuse_epoch;        // single-launch forward + dW: launch tag of the forward blocks' granules
     int fuse;                   // forward and dW of a linear bf16 head as one launch (default; UMLH_BF16_FUSE=0: two launches)
-    int dbg_step;               // UMLH_DBG_STEP=1: step_bf16 writes a per-block timeline into the debug buffer
+    int dbg_step;               // UMLH_DBG_STEP=1: step_bf16 writes a per-task timeline into the debug buffer
+    int step_lazy;              // UMLH_STEP_LAZY=1 (tests): see StepShape::lazy
+    int step_grid;              // persistent workgroups of the one-launch step (CUs of the device; UMLH_STEP_GRID overrides)
+    long long step_launches;    // one-launch steps taken (tests assert the path that ran)
     const HeadFuse* pending_head;   // set by train_step_impl: the update may ride in the same launch (step_bf16)
     bool head_fused_done;       // forward_backward took it
     // state carried from umlh_grad_step to umlh_apply_update
@@ -322,6 +328,8 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->fuse_epoch = 0;
     h->pending_head = nullptr; h->head_fused_done = false;
     { const char* e = getenv("UMLH_DBG_STEP"); h->dbg_step = (e && atoi(e) == 1) ? 1 : 0; }
+    h->step_grid = 0; h->step_launches = 0;
+    { const char* e = getenv("UMLH_STEP_LAZY"); h->step_lazy = (e && atoi(e) == 1) ? 1 : 0; }
     { const char* e = getenv("UMLH_BF16_FUSE"); h->fuse = e ? atoi(e) : 2; }   // 2 (default): the whole step as one launch; 1: forward + dW as one; 0: separate launches
     h->last_rows_img = h->last_rows_txt = 0;
     h->global_rows_img = h->global_rows_txt = 0;
@@ -336,6 +344,8 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     { const char* e = getenv("UMLH_MICRO"); h->micro_off = (e && atoi(e) == 0) ? 1 : 0; }
     h->device = 0;
     (void)hipGetDevice(&h->device);
+    h->step_grid = device_cus(h->device);
+    { const char* e = getenv("UMLH_STEP_GRID"); if (e && atoi(e) > 0) h->step_grid = atoi(e); }   // fewer workgroups than tasks is always correct (tests: partial residency)
     memset(&h->buf, 0, sizeof(h->buf));
     *out = h;
     return UMLH_OK;
@@ -418,10 +428,10 @@ int umlh_bind(umlh_handle_t h, const umlh_buffers_t* b) {
         const long long np = 4 * ((h->L.n_head + 1023) / 1024 + 2);
         if (hipMemset(ws(h, h->L.diag_part) + np, 0, 64 * sizeof(float)) != hipSuccess) return fail(UMLH_E_HIP, "umlh_bind: clearing the diagnostics ticket failed");
     }
-    if (h->L.fuse_flags) {        // granules of the single-launch forward + dW: tag 0 = never written
+    if (h->L.fuse_flags) {        // done granules / claim words / status of the one-launch step: tag 0 = never written
         DeviceGuard dg_(h->device);
-        if (hipMemset(ws(h, h->L.fuse_flags), 0, sizeof(float) * 2 * (size_t)(h->L.max_blocks + 8 + 4096)) != hipSuccess)
-            return fail(UMLH_E_HIP, "umlh_bind: clearing the forward granules failed");
+        if (hipMemset(ws(h, h->L.fuse_flags), 0, sizeof(float) * (size_t)(3 * h->L.ctl_tasks + 16)) != hipSuccess)
+            return fail(UMLH_E_HIP, "umlh_bind: clearing the step control words failed");
         h->fuse_epoch = 0;
     }
     if (h->L.fwd_nq) {            // exchange granules of the 2-D forward: tag 0 = never written
@@ -986,23 +996,29 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             g.k_chunk = sp.chunk; g.k_switch = r0p; g.k_valid1 = ri; g.k_valid2 = rt; g.slab_stride = L.n_head;
             g.nsplit = splits; g.nsplit1 = sp.n_img; h->n_slabs_img = sp.n_img;
             const int ndw_blocks = ((c.d_shared + 127) / 128) * ((c.num_classes + 127) / 128) * splits;
-            if (fused && h->pending_head && ndw_blocks <= 4096 && h->fuse >= 2) {
-                if (++h->fuse_epoch == 0) h->fuse_epoch = 1;
-                HeadFuse hf = *h->pending_head;
-                hf.n_slabs = splits; hf.n_slabs_img = sp.n_img;
-                HIPCHK(umlh_bf16_launch_step(&fb, h->ctw, h->wc, nb0 + nb1, &g, splits,
-                                             reinterpret_cast<unsigned long long*>(ws(h, L.fuse_flags)), h->fuse_epoch, TS,
-                                             (nb0 + nb1) * TS, &hf,
-                                             (h->dbg_step && 4LL * (nb0 + nb1 + ndw_blocks + L.n_head / 2048 + 4) <= 64LL * L.max_blocks)
-                                                 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr, st), "step_bf16");
-                h->head_fused_done = true;
-            } else if (fused) {
-                if (++h->fuse_epoch == 0) h->fuse_epoch = 1;
-                HIPCHK(umlh_bf16_launch_fwd_dw(&fb, h->ctw, h->wc, nb0 + nb1, &g, splits,
-                                               reinterpret_cast<unsigned long long*>(ws(h, L.fuse_flags)), h->fuse_epoch, TS,
-                                               (nb0 + nb1) * TS, st), "fwd_dw_bf16");
-            } else
-            HIPCHK(umlh_bf16_launch_dw(&g, splits, 0, 0, st), "dw_bf16");
+            const bool with_head = fused && h->pending_head && h->fuse >= 2;
+            if (fused && umlh_bf16_step_tasks(nb0 + nb1, g.M, g.N, splits, L.n_head, with_head) <= L.ctl_tasks) {
+                // forward + dW (+ update + finalize) as ONE launch of persistent workgroups over claimed tasks (StepCtl)
+                if (++h->fuse_epoch == 0) {                   // tag wrap (2^32 launches): start the epoch-tagged words over
+                    HIPCHK((int)hipMemsetAsync(ws(h, L.fuse_flags), 0, sizeof(float) * (size_t)(3 * L.ctl_tasks), st), "step control words");
+                    h->fuse_epoch = 1;
+                }
+                HeadFuse hf;
+                if (with_head) { hf = *h->pending_head; hf.n_slabs = splits; hf.n_slabs_img = sp.n_img; }
+                unsigned long long* done = reinterpret_cast<unsigned long long*>(ws(h, L.fuse_flags));
+                unsigned* claim = reinterpret_cast<unsigned*>(done + L.ctl_tasks);
+                unsigned* status = claim + L.ctl_tasks;
+                const int ntask = umlh_bf16_step_tasks(nb0 + nb1, g.M, g.N, splits, L.n_head, with_head);
+                HIPCHK(umlh_bf16_launch_step(&fb, h->ctw, h->wc, nb0 + nb1, &g, splits, claim, done, status, h->fuse_epoch, TS,
+                                             (nb0 + nb1) * TS, with_head ? &hf : nullptr,
+                                             (h->dbg_step && 4LL * ntask <= 64LL * L.max_blocks)
+                                                 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr, h->step_grid, h->step_lazy, st), "step_bf16");
+                h->head_fused_done = with_head;
+                h->step_launches++;
+            } else {
+                if (fused) HIPCHK(umlh_bf16_launch_fwd(&fb, h->ctw, h->wc, h->stw, nb0 + nb1, st), "fwd_ce_bf16");
+                HIPCHK(umlh_bf16_launch_dw(&g, splits, 0, 0, st), "dw_bf16");
+            }
             *n_slabs_head = splits;
         }
         mark(h, 3, st);
@@ -1388,6 +1404,24 @@ int umlh_micro_status(umlh_handle_t h, int32_t* status_out) {
     return UMLH_OK;
 }
 
+// status of the one-launch step's bounded waits: 0 = every wait of every step so far ended; else {code, first task of the range
+// waited on, epoch, phase} of the FIRST wait that gave up (the step that hit it and all later ones applied no update)
+int umlh_step_status(umlh_handle_t h, int32_t* status_out) {
+    if (!h || !h->bound || !status_out) return fail(UMLH_E_INVALID, "umlh_step_status: bad arguments");
+    status_out[0] = status_out[1] = status_out[2] = status_out[3] = 0;
+    if (!h->L.fuse_flags) return UMLH_OK;
+    DeviceGuard dg_(h->device);
+    const unsigned* st = reinterpret_cast<const unsigned*>(reinterpret_cast<unsigned long long*>(ws(h, h->L.fuse_flags)) + h->L.ctl_tasks) + h->L.ctl_tasks;
+    HIPCHK((int)hipMemcpy(status_out, st, 4 * sizeof(int32_t), hipMemcpyDeviceToHost), "umlh_step_status");
+    return UMLH_OK;
+}
+
+int umlh_step_launches(umlh_handle_t h, int64_t* out) {
+    if (!h || !out) return fail(UMLH_E_INVALID, "umlh_step_launches: bad arguments");
+    *out = h->step_launches;
+    return UMLH_OK;
+}
+
 int umlh_micro_launches(umlh_handle_t h, int64_t* out) {
     if (!h || !out) return fail(UMLH_E_INVALID, "umlh_micro_launches: bad arguments");
     *out = h->micro_launches;
@@ -1624,8 +1658,12 @@ static int dp_reduce_head(umlh_handle_t h, const umlh_batch_t* img, const umlh_b
         return UMLH_OK;
     }
     if (h->cfg.d_shared % 8 == 0) {
+        // image slabs and text slabs are summed separately, then added: the order of the fused step and of the one-launch
+        // gradient (step_update_task), so the message is bit-identical whichever launch form wrote it
+        DiagArgs order; order.dst = nullptr; order.n_slabs_img = h->n_slabs_img < sh ? h->n_slabs_img : sh;
+        order.inv_w0 = order.inv_w1 = 0.f; order.part = nullptr; order.ticket = nullptr;
         HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, nh, h->cfg.num_classes, h->cfg.d_shared, nullptr, nullptr, nullptr, &o,
-                                     nullptr, 32 * h->ctw * h->wc, &f, grads, nullptr, st), "reduce head");
+                                     nullptr, 32 * h->ctw * h->wc, &f, grads, &order, st), "reduce head");
     } else {
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
         HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, nh, nh, grads, nullptr, nullptr, nullptr, &o, 0, 0, st), "reduce head");

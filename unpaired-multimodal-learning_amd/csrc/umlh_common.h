@@ -293,6 +293,88 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
 }
 
+// --------------------------------------------------------------------------------------------------------------- //
+// Claimed tasks of a one-launch step (step_bf16, step_f32).  The launch is a grid of persistent workgroups; the work
+// is a list of TASKS (forward tiles, dW tiles, update slices, finalize) with dependencies that only point at earlier
+// phases.  Nothing here depends on dispatch order, workgroup -> XCD placement or on the whole grid being resident:
+//   * a task is run by whoever TAKES it: claim[t] = epoch via atomicMax, exactly one taker sees an older value;
+//   * a workgroup walks its home tasks (b, b + G, ...) phase by phase, so it only ever holds tasks of phases >= the
+//     one it is running;
+//   * before a workgroup WAITS for task t it looks at claim[t]: a task nobody has taken (its home workgroup is not
+//     resident yet: a second process / queue holds the CUs) is taken and run by the waiter itself, then the wait resumes.
+//     A wait is therefore always on a task held by a RESIDENT workgroup that is running it or a lower phase: by
+//     induction over the phases every wait ends (round 2 waited on lower block ids instead, which is only safe when
+//     this launch has the device to itself: gpurun_out/n2_*.log);
+//   * finished = done[t] granule {epoch, 1}, stored by one lane after every wave's write-through stores have drained.
+// All words are epoch-tagged (epoch = launch/step tag, strictly increasing per handle): nothing is reset between
+// launches.  Waits are bounded (50 ms); a wait that gives up sets status[0] (first code wins), the task and everything
+// behind it is skipped (no update is applied from a gradient that timed out) and the host reads the word
+// (umlh_step_status): umlh_train_step(s) does not return OK-with-NaN-weights any more.
+// --------------------------------------------------------------------------------------------------------------- //
+struct StepCtl {
+    unsigned* claim;             // [ntask]
+    unsigned long long* done;    // [ntask]
+    unsigned* status;            // [4]: code (0 = ok), task waited on, epoch, phase
+    unsigned epoch;              // never 0
+};
+constexpr int TW_OK = -1, TW_ABORT = -2;
+constexpr unsigned long long UMLH_SPIN_TICKS = 5000000ull;     // 50 ms of s_memrealtime (100 MHz)
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned ctl_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane takes task t; true = it is ours
+__device__ __forceinline__ bool task_take(const StepCtl& c, int t) {
+    return __hip_atomic_fetch_max(c.claim + t, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != c.epoch;
+}
+// Called by ONE whole wave: waits until tasks [first, first + count) are done.  Returns TW_OK, TW_ABORT (status set: by this
+// wait's time-out or by anybody else) or the id of a task of the range that nobody had taken and that this wave has now
+// TAKEN: the caller must run it (and may then wait again).
+__device__ __forceinline__ int tasks_wait(const StepCtl& c, int first, int count, int lane, unsigned phase) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spin = 0;; ++spin) {
+        const bool look = (spin & 7u) == 7u;
+        bool ok = true;
+        int untaken = 0x7fffffff;
+        for (int i = lane; i < count; i += 64) {
+            const unsigned long long v = __hip_atomic_load(c.done + first + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool d = (unsigned)(v >> 32) == c.epoch;
+            ok = ok && d;
+            if (look && !d && ctl_load_u32(c.claim + first + i) != c.epoch) untaken = min(untaken, first + i);
+        }
+        if (__all(ok)) return TW_OK;
+        if (look) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) untaken = min(untaken, __shfl_xor(untaken, off));
+            if (untaken != 0x7fffffff) {
+                unsigned old = c.epoch;
+                if (lane == 0) old = __hip_atomic_fetch_max(c.claim + untaken, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)__builtin_amdgcn_readfirstlane((int)old) != c.epoch) return untaken;
+            }
+            if (ctl_load_u32(c.status) != 0u) return TW_ABORT;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > UMLH_SPIN_TICKS) {
+                if (lane == 0) {
+                    unsigned expect = 0u;
+                    if (__hip_atomic_compare_exchange_strong(c.status, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(c.status + 1, (unsigned)first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(c.status + 2, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(c.status + 3, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                return TW_ABORT;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// every thread of the workgroup calls it after the task's last store: drain, barrier, one granule
+__device__ __forceinline__ void task_publish(const StepCtl& c, int t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(c.done + t, ((unsigned long long)c.epoch << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // everything the head blocks of the single-launch step need (step_bf16 in umlh_kernels_bf16.hip)
 struct HeadFuse {
     const float* slabs; int n_slabs, n_slabs_img; long long slab_stride; int C, K;

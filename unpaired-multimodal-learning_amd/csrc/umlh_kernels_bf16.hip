@@ -10,6 +10,8 @@
 //   dw_bf16        dW = dZ^T F with the k-strided operand read through ds_read_b64_tr_b16
 #include "umlh_common.h"
 #include <type_traits>
+#include <atomic>
+#include <cstring>
 
 // Timing-only ablations (skip the main loop / the epilogue / an operand's traffic) exist for kernel analysis and are
 // compiled in only with -DUMLH_ABLATIONS: the shipped library has no path that skips work.  The cycle stamps
@@ -903,12 +905,15 @@ __device__ __forceinline__ u32x4 load_coherent_b128(__amdgpu_buffer_rsrc_t rsrc,
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 1 << 4 /* sc1 */);
 }
 
-struct DwGate { const unsigned long long* flags; unsigned epoch; int ts, total_cols; unsigned long long* publish;   // publish: this launch's dW granules (or NULL)
-                unsigned long long* timeline; int tl_base; };   // UMLH_DBG_STEP=1: [block][4] s_memrealtime stamps (100 MHz): start, gate open, end
+struct DwGate { StepCtl ctl; int fwd_base, self_base;   // task ids of forward block 0 / dW block 0 of this launch
+                int ts, total_cols;
+                unsigned long long* timeline; };          // UMLH_DBG_STEP=1: [task][4] s_memrealtime stamps (100 MHz): start, gate open, end
 constexpr int DW_LDS_BYTES = 2 * DBM * RSA * 2 + 2 * DKT * RSF * 2 + DIDS * 4;   // two A tiles, two F tiles, the split's row ids
 
+// Returns TW_OK when the tile is written; GATED only: TW_ABORT (a wait gave up: nothing stored) or the id of a forward task
+// this workgroup has TAKEN while waiting (nobody held it): the caller runs it and calls again (nothing was stored yet).
 template <int AM, int OM, bool GATED>
-__device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, const DwGate& gate, unsigned char* lds) {
+__device__ __forceinline__ int dw_bf16_body(const DwArgsB& g, const int vbid, const DwGate& gate, unsigned char* lds, int* sh_rc) {
     // two LDS buffers: chunk c+1 is written while chunk c is consumed -> ONE barrier per chunk
     u16 (*At)[DBM * RSA] = reinterpret_cast<u16 (*)[DBM * RSA]>(lds);
     u16 (*Ft)[DKT * RSF] = reinterpret_cast<u16 (*)[DKT * RSF]>(lds + 2 * DBM * RSA * 2);
@@ -937,7 +942,7 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, c
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #define DSTAMP(i) do { if (g.stamps && lane == 0) g.stamps[((size_t)vbid * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     DSTAMP(0);
-    if (GATED && gate.timeline && tid == 0) gate.timeline[(size_t)(gate.tl_base + vbid) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    if (GATED && gate.timeline && tid == 0) gate.timeline[(size_t)(gate.self_base + vbid) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
 
     struct Stage { u32x4 a[2]; u32x4 f[2]; };
     Stage st[DNS];
@@ -1043,29 +1048,17 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, c
     for (int d = 0; d < DNS; ++d) gloadF(st[d], min(d, lastc));
     if (GATED) {
         // forward block b writes columns [b * ts, (b + 1) * ts) of dZ^T (image blocks first, text columns start at a multiple
-        // of ts); this split reads [kb, ke).  One sweep = all granules of the range in flight; bounded; a timed-out wait
-        // poisons the slab (NaN weights after the update) instead of hanging.
-        __shared__ int gate_bad;
-        if (tid == 0) gate_bad = 0;
+        // of ts); this split reads [kb, ke).  One sweep = all granules of the range in flight (tasks_wait, umlh_common.h).
         if (wave == 0) {
             const int b0 = kb / gate.ts, nb = (min(ke, gate.total_cols) - kb + gate.ts - 1) / gate.ts;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            bool bad = false;
-            for (unsigned spin = 0; !bad; ++spin) {
-                bool ok = true;
-                for (int i = lane; i < nb; i += 64) {
-                    const unsigned long long v = __hip_atomic_load(gate.flags + b0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && (unsigned)(v >> 32) == gate.epoch;
-                }
-                if (__all(ok)) break;
-                if ((spin & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) bad = true;   // 2 s at 100 MHz
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (bad && lane == 0) gate_bad = 1;
+            const int rc = nb > 0 ? tasks_wait(gate.ctl, gate.fwd_base + b0, nb, lane, 1u) : TW_OK;
+            if (lane == 0) *sh_rc = rc;
         }
         __syncthreads();
-        if (gate.timeline && tid == 0) gate.timeline[(size_t)(gate.tl_base + vbid) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-        if (gate_bad && tid == 0) g.out[(size_t)z * g.slab_stride] = __builtin_nanf("");
+        const int rc = *sh_rc;
+        __syncthreads();                                // (the word is rewritten by the next wait)
+        if (rc != TW_OK) return rc;
+        if (gate.timeline && tid == 0) gate.timeline[(size_t)(gate.self_base + vbid) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
         for (int d = 0; d < DNS; ++d) gloadA(st[d], min(d, lastc));
     }
@@ -1164,98 +1157,43 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgsB& g, const int vbid, c
             }
     }
     DSTAMP(7);
-    if (GATED && gate.timeline && tid == 0) gate.timeline[(size_t)(gate.tl_base + vbid) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-    if (GATED && gate.publish != nullptr) {              // the update blocks of the same launch wait for this split's slab
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) fq_store_granule(gate.publish + vbid, gate.epoch, 1.f);
-    }
+    if (GATED && gate.timeline && tid == 0) gate.timeline[(size_t)(gate.self_base + vbid) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    return TW_OK;
 #undef DSTAMP
 }
 
 template <int AM, int OM>
 __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     __shared__ __attribute__((aligned(16))) unsigned char dw_lds[DW_LDS_BYTES];
-    DwGate none = {nullptr, 0u, 32, 0, nullptr, nullptr, 0};
-    dw_bf16_body<AM, OM, false>(g, (int)blockIdx.x, none, dw_lds);
+    DwGate none;
+    none.ctl = StepCtl{nullptr, nullptr, nullptr, 0u}; none.fwd_base = none.self_base = 0; none.ts = 32; none.total_cols = 0; none.timeline = nullptr;
+    (void)dw_bf16_body<AM, OM, false>(g, (int)blockIdx.x, none, dw_lds, nullptr);
 }
 
 // --------------------------------------------------------------------------- //
-// forward + dW as ONE launch: blocks [0, nfwd) are the forward's, blocks [nfwd, nfwd + ndw) dW's.  The dispatcher hands out
-// workgroups in block order per XCD and one workgroup fills a CU (134 KB of LDS), so a dW workgroup starts on a CU when its
-// forward workgroup retires and never before every forward workgroup of its XCD has been dispatched: the only waits are dW's,
-// on forward blocks that are running or done.  A forward block publishes an epoch-tagged granule once its write-through
-// dZ^T stores have drained (s_waitcnt vmcnt(0) in every wave, workgroup barrier, one sc1 store).
+// The whole step of a linear bf16 head as ONE launch of persistent workgroups over CLAIMED TASKS (umlh_common.h, StepCtl):
+//   phase 0  forward tiles     [0, nfwd)                       fwd_ce_bf16_body, publishes after its write-through dZ^T stores
+//   phase 1  dW tiles          [nfwd, nfwd + ndw)              dw_bf16_body<GATED>: waits for the forward tiles of its K range
+//   phase 2  update slices     [nfwd + ndw, .. + nupd)         two 256-thread sub-blocks of head_step_kernel's work each (same
+//            + finalize        the last task                   arithmetic, same order); wait for the dW tiles of their 128-class
+//                                                              tile rows; finalize waits for every forward tile
+// nupd = 0: forward + dW only (the update is a separate launch: gradient diagnostics on).  hf.grad_out: the update slices
+// write the summed gradient (data-parallel split step) instead of stepping the weights.
+// Workgroup b runs its home tasks b, b + G, ... of each phase in phase order.  A task whose home workgroup has not arrived
+// is taken by the first workgroup that needs its result (tasks_wait), so no wait depends on dispatch order or residency.
+// Handed-off data (dZ^T, slabs, partials) is stored write-through and read with device-coherent loads.
 // --------------------------------------------------------------------------- //
-template <int CTW, int WC>
-__global__ __launch_bounds__(512) void fwd_dw_bf16(FwdArgsB a, DwArgsB g, DwGate gate, unsigned long long* flags, int nfwd) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    if ((int)blockIdx.x < nfwd) {
-        fwd_ce_bf16_body<CTW, WC, 1>(a, (int)blockIdx.x, smem_dyn);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) fq_store_granule(flags + blockIdx.x, gate.epoch, 1.f);
-    } else {
-        dw_bf16_body<0, 0, true>(g, (int)blockIdx.x - nfwd, gate, smem_dyn);   // the same dynamic LDS, laid out for dW
-    }
-}
-
-// --------------------------------------------------------------------------- //
-// the whole step as ONE launch: forward blocks, dW blocks (as in fwd_dw_bf16), then the update blocks and the finalize block.
-// An update workgroup = two 256-thread sub-blocks of head_step_kernel's work (4 consecutive elements per thread, same
-// arithmetic in the same order); it loads W, m, v first, then waits for the granules of the dW blocks of its 128-class tile
-// row(s) (column tiles x K splits), reads their slabs with device-coherent loads, updates and writes through.  The last
-// workgroup waits for every forward block's granule and forms the step scalars / logit-scale update from the forward's
-// partials.  Waits only ever point at lower block ids, which the in-order dispatcher has started before.
-// --------------------------------------------------------------------------- //
-__device__ __forceinline__ bool sweep_granules(const unsigned long long* fl, int first, int count, unsigned epoch, int lane, int stride) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (unsigned spin = 0;; ++spin) {
-        bool ok = true;
-        for (int i = lane; i < count; i += stride) {
-            const unsigned long long v = __hip_atomic_load(fl + first + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = ok && (unsigned)(v >> 32) == epoch;
-        }
-        if (__all(ok)) return true;
-        if ((spin & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) return false;   // 2 s at 100 MHz
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
+struct StepShape { int nfwd, ndw, nupd, nfin;
+                   int lazy; };   // test switch (UMLH_STEP_LAZY=1): every 4th workgroup leaves its forward and dW home tasks alone,
+                                  // as if it had not been dispatched yet -- whoever needs them takes them (tasks_wait)
 
 template <int CTW, int WC>
-__global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate gate, unsigned long long* flags, int nfwd, int ndw, HeadFuse hf) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    const int bid = (int)blockIdx.x;
-    unsigned long long* tl = gate.timeline ? gate.timeline + (size_t)bid * 4 : nullptr;
-    if (tl && threadIdx.x == 0 && (bid < nfwd || bid >= nfwd + ndw)) tl[0] = __builtin_amdgcn_s_memrealtime();
-    if (bid < nfwd) {
-        fwd_ce_bf16_body<CTW, WC, 1>(a, bid, smem_dyn);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) fq_store_granule(flags + bid, gate.epoch, 1.f);
-        if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
-        return;
-    }
-    if (bid < nfwd + ndw) {
-        dw_bf16_body<0, 0, true>(g, bid - nfwd, gate, smem_dyn);
-        return;
-    }
-    float (*sh)[256] = reinterpret_cast<float (*)[256]>(smem_dyn);
-    if (bid == (int)gridDim.x - 1) {                         // finalize: needs every forward block's partials
-        __shared__ int fin_bad;
-        if (threadIdx.x == 0) fin_bad = 0;
-        __syncthreads();
-        if (!sweep_granules(flags, 0, nfwd, gate.epoch, (int)threadIdx.x & 63, 64)) fin_bad = 1;   // every wave sweeps (cheap, one block)
-        __syncthreads();
-        FinalizeArgs f = hf.f;
-        if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
-        finalize_body<true>(f, sh);
-        if (fin_bad && threadIdx.x == 0 && f.tail) f.tail[2 + UMLH_S_LOSS_IMG] = __builtin_nanf("");
-        if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
-        return;
-    }
+__device__ __forceinline__ int step_update_task(const HeadFuse& hf, const DwGate& gate, const StepShape& sh, int u, int* sh_rc) {
+    const int t_self = sh.nfwd + sh.ndw + u;
+    unsigned long long* tl = gate.timeline ? gate.timeline + (size_t)t_self * 4 : nullptr;
+    if (tl && threadIdx.x == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
     // ---- update: sub-block `sub`, thread t of 256 ----
-    const int sub = 2 * (bid - nfwd - ndw) + ((int)threadIdx.x >> 8), t = (int)threadIdx.x & 255;
+    const int sub = 2 * u + ((int)threadIdx.x >> 8), t = (int)threadIdx.x & 255;
     const long long n4 = (long long)hf.C * hf.K / 4;
     const long long g4 = (long long)sub * 256 + t;
     const bool live = sub < hf.n_sub && g4 < n4;
@@ -1267,49 +1205,162 @@ __global__ __launch_bounds__(512) void step_bf16(FwdArgsB a, DwArgsB g, DwGate g
         m0 = *reinterpret_cast<f32x4v*>(hf.m + i);
         if (hf.o.kind != UMLH_OPT_SGD) v0 = *reinterpret_cast<f32x4v*>(hf.v + i);
     }
-    __shared__ int upd_bad;
-    if (threadIdx.x == 0) upd_bad = 0;
-    __syncthreads();
-    if ((t >> 6) == 0 && sub < hf.n_sub) {                   // wave 0 of the sub-block: granules of its tile row(s)
-        const long long e0 = (long long)sub * 1024, e1 = min(e0 + 1023, (long long)hf.C * hf.K - 1);
+    if ((int)threadIdx.x < 64) {                             // wave 0: the dW tiles of the workgroup's tile row(s)
+        const long long e0 = (long long)(2 * u) * 1024, e1 = min(e0 + 2047, (long long)hf.C * hf.K - 1);
         const int m_lo = (int)(e0 / hf.K) / 128, m_hi = (int)(e1 / hf.K) / 128;
-        if (!sweep_granules(gate.publish, m_lo * hf.dw_per_row, (m_hi - m_lo + 1) * hf.dw_per_row, gate.epoch, t & 63, 64)) upd_bad = 1;
+        const int rc = tasks_wait(gate.ctl, sh.nfwd + m_lo * hf.dw_per_row, (m_hi - m_lo + 1) * hf.dw_per_row, (int)threadIdx.x, 2u);
+        if (threadIdx.x == 0) *sh_rc = rc;
     }
     __syncthreads();
+    const int rc = *sh_rc;
+    __syncthreads();
+    if (rc != TW_OK) return rc;
     if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
-    if (!live) return;
-    {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hf.slabs), 0,
-                                                                      (int)((size_t)hf.n_slabs * hf.slab_stride * 4), 0x00020000);
-        for (int sI = 0; sI < hf.n_slabs_img; ++sI)
-            gi += __builtin_bit_cast(f32x4v, load_coherent_b128(rs, (unsigned)(((size_t)sI * hf.slab_stride + i) * 4)));
-        for (int sI = hf.n_slabs_img; sI < hf.n_slabs; ++sI)
-            gt += __builtin_bit_cast(f32x4v, load_coherent_b128(rs, (unsigned)(((size_t)sI * hf.slab_stride + i) * 4)));
-    }
-    const f32x4v g0 = gi + gt;
-    if (!upd) {
-        const float nanv = __builtin_nanf("");
-        store_out_f32x4(hf.grad_out + i, upd_bad ? f32x4v{nanv, nanv, nanv, nanv} : g0, 0);
-        if (tl && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[2] = __builtin_amdgcn_s_memrealtime(); }
-        return;
-    }
+    if (live) {
+        {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hf.slabs), 0,
+                                                                          (int)((size_t)hf.n_slabs * hf.slab_stride * 4), 0x00020000);
+            for (int sI = 0; sI < hf.n_slabs_img; ++sI)
+                gi += __builtin_bit_cast(f32x4v, load_coherent_b128(rs, (unsigned)(((size_t)sI * hf.slab_stride + i) * 4)));
+            for (int sI = hf.n_slabs_img; sI < hf.n_slabs; ++sI)
+                gt += __builtin_bit_cast(f32x4v, load_coherent_b128(rs, (unsigned)(((size_t)sI * hf.slab_stride + i) * 4)));
+        }
+        const f32x4v g0 = gi + gt;
+        if (!upd) {
+            store_out_f32x4(hf.grad_out + i, g0, 0);
+        } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float pa = p0[j], mb = m0[j], vc = v0[j];
-        opt_update(hf.o, upd_bad ? __builtin_nanf("") : g0[j], pa, mb, vc);
-        p0[j] = pa; m0[j] = mb; v0[j] = vc;
-    }
-    store_out_f32x4(hf.p + i, p0, 0);
-    store_out_f32x4(hf.m + i, m0, 0);
-    if (hf.o.kind != UMLH_OPT_SGD) store_out_f32x4(hf.v + i, v0, 0);
-    if (hf.shadow != nullptr) {
-        const int cls = (int)(i / hf.K), k = (int)(i % hf.K);
-        const long long piece = ((long long)(k >> 4) * (hf.cpad / 32) + (cls >> 5)) * 64 + (cls & 31) + 32 * ((k >> 3) & 1);
-        typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
-        const u32x2s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3])};
-        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(hf.shadow + piece * 8 + (k & 7)), "v"(w) : "memory");
+            for (int j = 0; j < 4; ++j) {
+                float pa = p0[j], mb = m0[j], vc = v0[j];
+                opt_update(hf.o, g0[j], pa, mb, vc);
+                p0[j] = pa; m0[j] = mb; v0[j] = vc;
+            }
+            store_out_f32x4(hf.p + i, p0, 0);
+            store_out_f32x4(hf.m + i, m0, 0);
+            if (hf.o.kind != UMLH_OPT_SGD) store_out_f32x4(hf.v + i, v0, 0);
+            if (hf.shadow != nullptr) {
+                const int cls = (int)(i / hf.K), k = (int)(i % hf.K);
+                const long long piece = ((long long)(k >> 4) * (hf.cpad / 32) + (cls >> 5)) * 64 + (cls & 31) + 32 * ((k >> 3) & 1);
+                typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+                const u32x2s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3])};
+                asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(hf.shadow + piece * 8 + (k & 7)), "v"(w) : "memory");
+            }
+        }
     }
     if (tl && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[2] = __builtin_amdgcn_s_memrealtime(); }
+    return TW_OK;
+}
+
+struct StepArgs { FwdArgsB a; DwArgsB g; DwGate gate; StepShape sh; HeadFuse hf; };   // THE kernel argument (one struct: the cold
+                                                                                       // path below re-reads it from the kernarg segment)
+template <int CTW, int WC>
+__device__ __forceinline__ void step_fwd_task(const StepArgs& p, int t, unsigned char* smem) {
+    unsigned long long* tl = p.gate.timeline ? p.gate.timeline + (size_t)t * 4 : nullptr;
+    if (tl && threadIdx.x == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
+    fwd_ce_bf16_body<CTW, WC, 1>(p.a, t, smem);
+    if (tl && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[2] = __builtin_amdgcn_s_memrealtime(); }
+    task_publish(p.gate.ctl, t);
+}
+
+template <int CTW, int WC>
+__device__ __forceinline__ int step_fin_task(const StepArgs& p, int t, unsigned char* smem, int* sh_ctl) {
+    unsigned long long* tl = p.gate.timeline ? p.gate.timeline + (size_t)t * 4 : nullptr;
+    if (tl && threadIdx.x == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
+    if ((int)threadIdx.x < 64) {
+        const int w = tasks_wait(p.gate.ctl, 0, p.sh.nfwd, (int)threadIdx.x, 3u);
+        if (threadIdx.x == 0) sh_ctl[0] = w;
+    }
+    __syncthreads();
+    const int rc = sh_ctl[0];
+    __syncthreads();
+    if (rc != TW_OK) return rc;
+    if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+    finalize_body<true>(p.hf.f, reinterpret_cast<float (*)[256]>(smem));
+    if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+    return TW_OK;
+}
+
+// COLD path, not inlined (its copies of the bodies and its loops must not take part in the register allocation of the hot,
+// straight-line kernel below; it re-reads the kernel argument from the kernarg segment).  Runs `first` (a task this workgroup
+// has TAKEN: one that a wait handed back because nobody held it, or -- take = 1 -- a home task beyond the first of a phase,
+// which is taken here) and then `then` (the home task whose wait was interrupted; -1 = none), each to completion; a wait in
+// either can hand back a lower-phase task again, which runs first (depth: update -> dW -> forward).
+template <int CTW, int WC>
+__device__ __attribute__((noinline)) void step_cold(const StepArgs* kp, int first, int then, int take, unsigned char* smem, int* sh_ctl) {
+    const StepArgs& p = *kp;
+    const StepCtl& ctl = p.gate.ctl;
+    const int b_dw = p.sh.nfwd, b_upd = p.sh.nfwd + p.sh.ndw, b_fin = p.sh.nfwd + p.sh.ndw + p.sh.nupd;
+    if (take) {
+        if (threadIdx.x == 0) sh_ctl[1] = task_take(ctl, first) ? 1 : 0;
+        __syncthreads();
+        const int mine = sh_ctl[1];
+        __syncthreads();
+        if (!mine) return;
+    }
+    // pending tasks, innermost last: s0 (= `then`, or `first`), s1, s2 (registers, no private array)
+    int s0 = then >= 0 ? then : first, s1 = then >= 0 ? first : -1, s2 = -1;
+    int sp = then >= 0 ? 2 : 1;
+    while (sp > 0) {
+        const int t = sp == 1 ? s0 : (sp == 2 ? s1 : s2);
+        int rc = TW_OK;
+        if (t < b_dw) { step_fwd_task<CTW, WC>(p, t, smem); --sp; continue; }
+        else if (t < b_upd) rc = dw_bf16_body<0, 0, true>(p.g, t - b_dw, p.gate, smem, sh_ctl);
+        else if (t < b_fin) rc = step_update_task<CTW, WC>(p.hf, p.gate, p.sh, t - b_upd, sh_ctl);
+        else rc = step_fin_task<CTW, WC>(p, t, smem, sh_ctl);
+        if (rc == TW_OK) { task_publish(ctl, t); --sp; }
+        else if (rc == TW_ABORT) { __syncthreads(); sp = 0; }    // status is set: these tasks and what depends on them are skipped
+        else { if (sp == 1) s1 = rc; else s2 = rc; ++sp; }       // (depth <= 3: update -> dW -> forward)
+    }
+}
+
+// HOT path: straight-line -- the first home task of each phase inline (a grid as wide as the phases, the normal case, has no
+// other), in execution order forward, dW, finalize (needs the forward tiles only; its home is the LAST workgroup, which has
+// no update slice when the grid is wider than the update), update.
+template <int CTW, int WC>
+__global__ __launch_bounds__(512) void step_bf16(StepArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    __shared__ int sh_ctl[8];                                // [0] wait verdict, [1] take verdict (cold path), [4..7] this workgroup's first home
+                                                             // task of each phase: taken or not (32 bytes of static LDS: the dynamic base stays 16-byte aligned)
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const StepCtl& ctl = p.gate.ctl;
+    const StepArgs* kp = (const StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();   // for the cold path: it reads the argument from there
+    const int b_dw = p.sh.nfwd, b_upd = p.sh.nfwd + p.sh.ndw, b_fin = p.sh.nfwd + p.sh.ndw + p.sh.nupd;   // task ids: forward, dW, update, finalize
+    const bool lazy = p.sh.lazy && (b & 3) == 1;
+    // all first home tasks are taken NOW, by four lanes of one instruction: the takes of the later phases cost nothing when
+    // their turn comes, and nobody who waits for one of them finds it untaken while this workgroup is still in an earlier phase
+    if (threadIdx.x < 4) {
+        const int k = (int)threadIdx.x;
+        int t = -1;
+        if (k == 0 && !lazy && b < p.sh.nfwd) t = b;
+        if (k == 1 && !lazy && b < p.sh.ndw) t = b_dw + b;
+        if (k == 2 && p.sh.nfin > 0 && b == G - 1) t = b_fin;
+        if (k == 3 && b < p.sh.nupd) t = b_upd + b;
+        sh_ctl[4 + k] = (t >= 0 && task_take(ctl, t)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (sh_ctl[4]) step_fwd_task<CTW, WC>(p, b, smem_dyn);
+#pragma unroll 1
+    for (int i = b + G; i < p.sh.nfwd && !lazy; i += G) step_cold<CTW, WC>(kp, i, -1, 1, smem_dyn, sh_ctl);
+    if (sh_ctl[5]) {
+        const int rc = dw_bf16_body<0, 0, true>(p.g, b, p.gate, smem_dyn, sh_ctl);   // the same dynamic LDS, laid out for dW
+        if (rc == TW_OK) task_publish(ctl, b_dw + b);
+        else if (rc == TW_ABORT) __syncthreads();            // status is set: this task and what depends on it is skipped
+        else step_cold<CTW, WC>(kp, rc, b_dw + b, 0, smem_dyn, sh_ctl);   // a forward tile nobody had taken: run it, then this tile from the start (nothing was stored)
+    }
+#pragma unroll 1
+    for (int i = b + G; i < p.sh.ndw && !lazy; i += G) step_cold<CTW, WC>(kp, b_dw + i, -1, 1, smem_dyn, sh_ctl);
+    if (sh_ctl[6]) {
+        const int rc = step_fin_task<CTW, WC>(p, b_fin, smem_dyn, sh_ctl);
+        if (rc == TW_OK) task_publish(ctl, b_fin);
+        else if (rc >= 0) step_cold<CTW, WC>(kp, rc, b_fin, 0, smem_dyn, sh_ctl);
+    }
+    if (sh_ctl[7]) {
+        const int rc = step_update_task<CTW, WC>(p.hf, p.gate, p.sh, b, sh_ctl);
+        if (rc == TW_OK) task_publish(ctl, b_upd + b);
+        else if (rc >= 0) step_cold<CTW, WC>(kp, rc, b_upd + b, 0, smem_dyn, sh_ctl);   // a dW tile nobody had taken
+    }
+#pragma unroll 1
+    for (int i = b + G; i < p.sh.nupd; i += G) step_cold<CTW, WC>(kp, b_upd + i, -1, 1, smem_dyn, sh_ctl);
 }
 
 // --------------------------------------------------------------------------- //
@@ -1348,14 +1399,14 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
 #define FWDB_CASE(CT, W, S)                                                                          \
     if (ctw == CT && wc == W && stw == S) {                                                          \
         size_t sm = fwd_smem_bytes_b(CT, W, S);                                                      \
-        static unsigned long long attr_done = 0;           /* bit d: done on device d (the attribute is per device) */ \
+        static std::atomic<unsigned long long> attr_done{0};  /* bit d: done on device d (the attribute is per device) */ \
         int dev_ = 0;                                                                                \
         (void)hipGetDevice(&dev_);                                                                   \
-        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                  \
+        if (!((attr_done.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ULL)) {                  \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_bf16<CT, W, S>),\
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
             if (e != hipSuccess) return (int)e;                                                      \
-            attr_done |= 1ULL << (dev_ & 63);                                                        \
+            attr_done.fetch_or(1ULL << (dev_ & 63), std::memory_order_release);                      \
         }                                                                                            \
         FwdArgsB c_ = *a; c_.plain = umlh_plain_stores();                                            \
         hipLaunchKernelGGL((fwd_ce_bf16<CT, W, S>), dim3(grid), dim3(512), sm, stream, c_);          \
@@ -1365,12 +1416,12 @@ static size_t fwd_smem_bytes_b(int ctw, int wc, int stw) {
 // 2-D forward: grid = row tiles (128 rows; seg[].blk0 in tile units) x nq class groups of 256
 #define FWDQ_CASE(NQ_, NKS_)                                                                                       \
     if (nq == NQ_ && a->K == 16 * NKS_) {                                                                          \
-        static unsigned long long attr_done = 0;                                                                   \
-        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                                \
+        static std::atomic<unsigned long long> attr_done{0};                                                       \
+        if (!((attr_done.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ULL)) {                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_bf16_q<NQ_, NKS_>),           \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, FQ_SMEM);               \
             if (e != hipSuccess) return (int)e;                                                                    \
-            attr_done |= 1ULL << (dev_ & 63);                                                                      \
+            attr_done.fetch_or(1ULL << (dev_ & 63), std::memory_order_release);                                    \
         }                                                                                                          \
         FwdArgsB c_ = *a; c_.plain = umlh_plain_stores();                                                          \
         hipLaunchKernelGGL((fwd_ce_bf16_q<NQ_, NKS_>), dim3((tiles + 7) / 8 * 8 * NQ_), dim3(512), FQ_SMEM, stream, c_);        \
@@ -1407,68 +1458,58 @@ int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, 
     if (ctw == CT && wc == W) {                                                                                    \
         size_t sm = fwd_smem_bytes_b(CT, W, 1);                                                                    \
         if (sm < (size_t)DW_LDS_BYTES) sm = DW_LDS_BYTES;                                                          \
-        static unsigned long long attr_done = 0;                                                                   \
-        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                                \
+        static std::atomic<unsigned long long> attr_done{0};  /* bit d: done on device d (the attribute is per device) */ \
+        if (!((attr_done.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ULL)) {                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_bf16<CT, W>),                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);               \
             if (e != hipSuccess) return (int)e;                                                                    \
-            attr_done |= 1ULL << (dev_ & 63);                                                                      \
+            attr_done.fetch_or(1ULL << (dev_ & 63), std::memory_order_release);                                    \
         }                                                                                                          \
-        hipLaunchKernelGGL((step_bf16<CT, W>), dim3(nfwd + ndw + nhead + 1), dim3(512), sm, stream, fa, ga, gate, flags, nfwd, ndw, h); \
+        hipLaunchKernelGGL((step_bf16<CT, W>), dim3(grid), dim3(512), sm, stream, sa);           \
         return (int)hipGetLastError();                                                                             \
     }
 
-// forward, dW and the update + finalize in one launch; flags: [nfwd] forward granules, then [ndw] dW granules
-int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
-                          unsigned epoch, int ts, int total_cols, const HeadFuse* hf, unsigned long long* timeline, hipStream_t stream) {
-    if (nfwd <= 0 || g->M <= 0 || g->N <= 0 || !flags || epoch == 0 || !a->dzt || !hf) return (int)hipErrorInvalidValue;
+// forward, dW and (hf != NULL) the update + finalize in one launch of `grid` persistent workgroups over claimed tasks.
+// claim: [ntask] u32, done: [ntask] u64, status: [4] u32 (device words, epoch-tagged: never reset); *ntask_out = tasks of the launch.
+int umlh_bf16_step_tasks(int nfwd, int M, int N, int splits, long long n_head, int with_head) {
+    const int ndw = ((N + DBN - 1) / DBN) * ((M + DBM - 1) / DBM) * splits;
+    const int n_sub = (int)((n_head / 4 + 255) / 256);
+    return nfwd + ndw + (with_head ? (n_sub + 1) / 2 + 1 : 0);
+}
+
+int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned* claim,
+                          unsigned long long* done, unsigned* status, unsigned epoch, int ts, int total_cols, const HeadFuse* hf,
+                          unsigned long long* timeline, int cus, int lazy, hipStream_t stream) {
+    if (nfwd <= 0 || g->M <= 0 || g->N <= 0 || !claim || !done || !status || epoch == 0 || !a->dzt) return (int)hipErrorInvalidValue;
     if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
     if (g->k_switch % DKT != 0 || g->bcs < 64 || g->N % 8 != 0 || umlh_plain_stores()) return (int)hipErrorInvalidValue;
-    if (hf->K % 8 != 0 || hf->C != g->M || hf->K != g->N || hf->slab_stride % 4 != 0) return (int)hipErrorInvalidValue;
+    if (hf && (hf->K % 8 != 0 || hf->C != g->M || hf->K != g->N || hf->slab_stride % 4 != 0)) return (int)hipErrorInvalidValue;
     const int nx = (g->N + DBN - 1) / DBN;
     const int ndw = nx * ((g->M + DBM - 1) / DBM) * splits;
     FwdArgsB fa = *a; fa.plain = 0;
     DwArgsB ga = *g; ga.plain = 0;
-    HeadFuse h = *hf;
-    const long long n4 = (long long)h.C * h.K / 4;
-    h.n_sub = (int)((n4 + 255) / 256);
-    h.dw_per_row = nx * splits;
-    const int nhead = (h.n_sub + 1) / 2;
-    DwGate gate = {flags, epoch, ts, total_cols, flags + nfwd, timeline, nfwd};
+    HeadFuse h;
+    memset(&h, 0, sizeof(h));
+    StepShape shp = {nfwd, ndw, 0, 0, lazy};
+    if (hf) {
+        h = *hf;
+        const long long n4 = (long long)h.C * h.K / 4;
+        h.n_sub = (int)((n4 + 255) / 256);
+        h.dw_per_row = nx * splits;
+        shp.nupd = (h.n_sub + 1) / 2;
+        shp.nfin = 1;
+    }
+    DwGate gate;
+    gate.ctl = StepCtl{claim, done, status, epoch};
+    gate.fwd_base = 0; gate.self_base = nfwd; gate.ts = ts; gate.total_cols = total_cols; gate.timeline = timeline;
+    int grid = nfwd > ndw ? nfwd : ndw;
+    if (shp.nupd + 1 > grid) grid = shp.nupd + 1;
+    if (cus > 0 && grid > cus) grid = cus;
+    StepArgs sa;
+    sa.a = fa; sa.g = ga; sa.gate = gate; sa.sh = shp; sa.hf = h;
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     STEP_CASE(1, 1) STEP_CASE(1, 2) STEP_CASE(1, 4) STEP_CASE(1, 8) STEP_CASE(2, 8) STEP_CASE(4, 8)
-    return (int)hipErrorInvalidValue;
-}
-
-#define FWD_DW_CASE(CT, W)                                                                                         \
-    if (ctw == CT && wc == W) {                                                                                    \
-        size_t sm = fwd_smem_bytes_b(CT, W, 1);                                                                    \
-        if (sm < (size_t)DW_LDS_BYTES) sm = DW_LDS_BYTES;                                                          \
-        static unsigned long long attr_done = 0;                                                                   \
-        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_dw_bf16<CT, W>),                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);               \
-            if (e != hipSuccess) return (int)e;                                                                    \
-            attr_done |= 1ULL << (dev_ & 63);                                                                      \
-        }                                                                                                          \
-        hipLaunchKernelGGL((fwd_dw_bf16<CT, W>), dim3(nfwd + ndw), dim3(512), sm, stream, fa, ga, gate, flags, nfwd); \
-        return (int)hipGetLastError();                                                                             \
-    }
-
-// forward (1-D kernel, one sample tile per wave) and dW (AM 0, OM 0) in one launch; see fwd_dw_bf16
-int umlh_bf16_launch_fwd_dw(const FwdArgsB* a, int ctw, int wc, int nfwd, const DwArgsB* g, int splits, unsigned long long* flags,
-                            unsigned epoch, int ts, int total_cols, hipStream_t stream) {
-    if (nfwd <= 0 || g->M <= 0 || g->N <= 0 || !flags || epoch == 0 || !a->dzt) return (int)hipErrorInvalidValue;
-    if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
-    if (g->k_switch % DKT != 0 || g->bcs < 64 || g->N % 8 != 0 || umlh_plain_stores()) return (int)hipErrorInvalidValue;
-    const int ndw = ((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits;
-    FwdArgsB fa = *a; fa.plain = 0;
-    DwArgsB ga = *g; ga.plain = 0;
-    DwGate gate = {flags, epoch, ts, total_cols, nullptr, nullptr, 0};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    FWD_DW_CASE(1, 1) FWD_DW_CASE(1, 2) FWD_DW_CASE(1, 4) FWD_DW_CASE(1, 8) FWD_DW_CASE(2, 8) FWD_DW_CASE(4, 8)
     return (int)hipErrorInvalidValue;
 }
 

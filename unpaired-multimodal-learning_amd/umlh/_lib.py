@@ -25,7 +25,7 @@ EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_f
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_eval_rows", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
-           "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_comm_unique_id", "umlh_comm_init_rank",
+           "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_step_status", "umlh_step_launches", "umlh_comm_unique_id", "umlh_comm_init_rank",
            "umlh_set_comm", "umlh_set_allreduce", "umlh_seq_mse_forward", "umlh_seq_mse_backward", "umlh_seq_mse_backward_scratch_floats", "umlh_infonce_forward", "umlh_infonce_backward",
            "umlh_random_permutation", "umlh_debug_buffer",
            "umlh_gemm_f32", "umlh_add_inplace", "umlh_bias_act", "umlh_relu_backward", "umlh_dropout", "umlh_colsum",
@@ -184,6 +184,8 @@ def load_library():
     lib.umlh_train_steps_grouped.argtypes = [C.POINTER(GroupItem), i32, i32, vp]
     lib.umlh_micro_status.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.umlh_micro_launches.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.umlh_step_status.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.umlh_step_launches.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.umlh_comm_unique_id.argtypes = [vp]
     lib.umlh_comm_init_rank.argtypes = [vp, vp, i32, i32]
     lib.umlh_set_comm.argtypes = [vp, vp, i32]

@@ -332,6 +332,31 @@ class HeadEngine:
         check(self.lib.umlh_micro_status(self.handle, C.byref(v)), "umlh_micro_status")
         return int(v.value)
 
+    def step_launches(self) -> int:
+        """One-launch steps (forward, dW and update as claimed tasks of ONE launch) this engine has taken."""
+        v = C.c_int64(0)
+        check(self.lib.umlh_step_launches(self.handle, C.byref(v)), "umlh_step_launches")
+        return int(v.value)
+
+    def step_status(self):
+        """(code, task, launch tag, phase) of the first bounded in-launch wait of the one-launch step that gave up; code 0 =
+        none did (host sync)."""
+        v = (C.c_int32 * 4)()
+        check(self.lib.umlh_step_status(self.handle, v), "umlh_step_status")
+        return tuple(int(x) for x in v)
+
+    def check_status(self) -> None:
+        """Raise UmlhError if an in-launch wait of this engine's kernels has given up (the device was starved by another
+        tenant, or a fault): steps from that point on applied no update.  Host sync; called wherever step scalars are read."""
+        st = self.micro_status()
+        if st != 0:
+            raise UmlhError(f"micro-step kernel gave up waiting at step {st - 1} of a call (another process starving the "
+                            "device of CUs?); the state of this head is undefined")
+        code, task, tag, phase = self.step_status()
+        if code != 0:
+            raise UmlhError(f"one-launch step: a wait on task {task} (phase {phase}, launch tag {tag}) gave up after 50 ms "
+                            "(another process starving the device of CUs?); no update was applied from that step on")
+
     def grad_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], alpha: float = 1.0,
                   img_alpha: float = 1.0, weights_unchanged: bool = False) -> torch.Tensor:
         """``weights_unchanged=True``: the caller guarantees nobody but this engine wrote w_head since its
