@@ -313,11 +313,11 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->bound = false;
     h->ts = umlh_f32_fwd_config(cfg->num_classes, &h->ctw, &h->wc);
     h->stw = 1;
+    { const char* d = getenv("UMLH_DBG_FWD"); h->dbg_fwd = d ? atoi(d) : 0; }
+    { const char* d = getenv("UMLH_DBG_DW"); h->dbg_dw = d ? atoi(d) : 0; }
     if (cfg->precision == UMLH_PREC_BF16) {
         // two 32-sample tiles per wave would halve the L2->CU stream of the head weight, but measured
         // slower on MI355X (51 vs 26 us at cfg2: half the CUs idle, VGPR-limited ring) -> opt-in only
-        { const char* d = getenv("UMLH_DBG_FWD"); h->dbg_fwd = d ? atoi(d) : 0; }
-        { const char* d = getenv("UMLH_DBG_DW"); h->dbg_dw = d ? atoi(d) : 0; }
         const char* e = getenv("UMLH_BF16_STW");
         int want = e ? atoi(e) : 1;
         if (h->wc == 8 && h->ctw >= 2 && want == 2) h->stw = 2;
@@ -1082,6 +1082,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     fa.dzt = want_grad ? dzt : nullptr; fa.ldz = L.ldz;
     fa.partials = ws(h, L.partials);
     fa.row_stats = h->row_stats;
+    fa.stamps = h->dbg_fwd == 9 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
     HIPCHK(umlh_f32_launch_fwd(&fa, h->ctw, h->wc, nb0 + nb1, st), "fwd_ce");
     mark(h, 2, st);
     if (!want_grad) return UMLH_OK;

@@ -62,6 +62,7 @@ struct FwdArgs {
     float* partials;             // [grid][4] = {loss_sum, correct, gscale_sum, 0}
     int   plain;                 // 1 = plain stores for dZ^T (default 0: write-through, see store_wt_f32)
     float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
+    unsigned long long* stamps;  // diagnostics (UMLH_DBG_FWD=9): [grid][8 waves][8] cycle stamps, else NULL
 };
 
 // Elementwise tail of a dense layer of the MultiBench encoder, applied to v = alpha * sum (element (m, n), flat index

@@ -7,6 +7,7 @@
 // latency/HBM-bound row kernels -- one wave per token row, LDS only where rows are shared (attention);
 // nothing here is reshaped to reach MFMA.
 #include "umlh_common.h"
+#include <atomic>
 
 namespace {
 
@@ -652,12 +653,14 @@ int umlh_enc_launch_attention_fwd(const float* qkv, const int64_t* lengths, int 
     if (T < 1 || T > ATM || H < 1 || Z % H != 0 || Z / H > ADH) return (int)hipErrorInvalidValue;
     const int rs = (Z / H) | 1;
     const size_t smem = sizeof(float) * (3 * (size_t)T * rs + AW * T);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_done{0};      // bit d: done on device d (the attribute is per device)
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ULL)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done.fetch_or(1ULL << (dev_ & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(64 * AW), smem, st, qkv, lengths, T, B, Z, H, drop_thresh(p),
                        p > 0.f ? 1.f / (1.f - p) : 1.f, seed, seed_ptr, ctx, lse);
@@ -670,12 +673,14 @@ int umlh_enc_launch_attention_bwd(const float* qkv, const int64_t* lengths, cons
     if (T < 1 || T > ATM || H < 1 || Z % H != 0 || Z / H > ADH) return (int)hipErrorInvalidValue;
     const int rs = (Z / H) | 1;
     const size_t smem = sizeof(float) * (4 * (size_t)T * rs + 2 * T + AW * 2 * T);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_done{0};      // bit d: done on device d (the attribute is per device)
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ULL)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done.fetch_or(1ULL << (dev_ & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(64 * AW), smem, st, qkv, lengths, lse, dctx, T, B, Z, H, drop_thresh(p),
                        p > 0.f ? 1.f / (1.f - p) : 1.f, seed, seed_ptr, dqkv);

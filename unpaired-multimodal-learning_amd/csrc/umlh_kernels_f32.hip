@@ -14,6 +14,7 @@
 //   zero_shot      head.py:22-37
 #include "umlh_common.h"
 #include <cstdlib>
+#include <atomic>
 
 // --------------------------------------------------------------------------- //
 // staging helpers: global -> registers -> LDS, k-major LDS tiles [KT][LD]
@@ -57,7 +58,9 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     // barrier per chunk (the 64-cycle fp32 MFMAs of the partner wave cover the ds_write_b32 stream)
     constexpr int BUF = KT * (LDW + LDX);
     float* Ws0 = smem;                    // [2][KT][LDW] then [KT][LDX]
-    float* red = smem + 2 * BUF;          // [WC][TS][4]
+    constexpr int STG = 8 * CTW * 32 * 32;                                  // epilogue: dZ staging, 8 waves x [CTW*32][32] floats (aliases the tile buffers)
+    constexpr int TILE = 2 * BUF > STG ? 2 * BUF : STG;
+    float* red = smem + TILE;             // [WC][TS][4]
     float* red2 = red + WC * TS * 4;      // [WS][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,6 +70,8 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     const SegDesc& sg = a.seg[sidx];
     const int row0 = ((int)blockIdx.x - sg.blk0) * TS;
     const int C = a.C, K = a.K;
+#define STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    STAMP(0);
     const bool vecW = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
     const bool vecX = (sg.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.feats) & 15) == 0);
 
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     lstore(0);
     if (FAST) gload(min(KT, K - KT)); else if (KT < K) gload(KT);
     __syncthreads();
+    STAMP(1);
     int buf = 0;
     for (int k0 = 0; k0 < K; k0 += KT) {
         if (k0 + KT < K) lstore(buf ^ 1);                // chunk c+1 -> the other buffer (its readers passed the last barrier)
@@ -212,24 +218,62 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
         buf ^= 1;
     }
 
+    STAMP(2);
     // ---------------- epilogue: softmax cross entropy on the register tile ----------------
+    // VALU-bound (16*CTW logits per lane, two waves per SIMD): round 3 rewrote it after the bf16 kernel's -- max by v_max3
+    // chains, first arg-max by a descending equality scan with the register number as an inline constant, label logit by a
+    // select tree on the bits of its register number, exp(u) as exp2(u * log2 e) on the exact u = fma(raw, scale, -max)
+    // (the v_exp_f32 result is 1 ulp; the product's rounding is 6e-8 |u log2 e|, i.e. < 3e-6 relative on every term that is
+    // not negligible against the max term: below the noise of the accumulation order, far below the 1e-4 this mode carries),
+    // dZ staged through the (now free) LDS tile buffers and stored 16 B per lane = 8 class rows x 128 B per instruction
+    // instead of 64 scattered 4-byte write-through stores per lane.  Padded classes (cls >= C) are handled in wave-uniform
+    // branches that only the tile straddling C takes.
     const float scale = *sg.scale_ptr;
     const int smp = ws * 32 + l31;
     const int r = row0 + smp;
     const bool valid = r < sg.rows;
     const int lab = valid ? lab_pre : -1;
-
+    constexpr int NREG = CTW * 16;
+    const int wave_c0 = wc * CTW * 32;
     const float NEG_INF = -__builtin_huge_valf();
-    float mx = NEG_INF;
-    int mi = 0x7fffffff;
+    const float LOG2E = 1.4426950408889634f;
+
+    // z = raw * scale in place of raw is NOT kept (raw is needed for d loss / d scale): each pass forms it again (one multiply)
+    float mx;
+    int mi;
+    {
+        float mkc[CTW];
 #pragma unroll
-    for (int ct = 0; ct < CTW; ++ct)
+        for (int ct = 0; ct < CTW; ++ct) {
+            const int cbase = wave_c0 + ct * 32;
+            if (cbase + 32 > C) {                          // wave-uniform: the tile that straddles C (or lies past it)
+                mkc[ct] = NEG_INF;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
-            float v = cls < C ? acc[ct][i] * scale : NEG_INF;
-            if (v > mx) { mx = v; mi = cls; }
+                for (int i = 0; i < 16; ++i) mkc[ct] = __builtin_fmaxf(mkc[ct], cbase + acc_row(i, h) < C ? acc[ct][i] * scale : NEG_INF);
+            } else {
+                mkc[ct] = acc[ct][0] * scale;
+#pragma unroll
+                for (int i = 1; i < 16; ++i) mkc[ct] = __builtin_fmaxf(mkc[ct], acc[ct][i] * scale);
+            }
         }
+        mx = mkc[0];
+#pragma unroll
+        for (int ct = 1; ct < CTW; ++ct) mx = __builtin_fmaxf(mx, mkc[ct]);
+        // first register (= lowest class of this lane) that holds the lane's max
+        int first = NREG;
+#pragma unroll
+        for (int ct = CTW - 1; ct >= 0; --ct) {
+            const int cbase = wave_c0 + ct * 32;
+            if (cbase + 32 > C) {
+#pragma unroll
+                for (int i = 15; i >= 0; --i) first = (cbase + acc_row(i, h) < C && acc[ct][i] * scale == mx) ? ct * 16 + i : first;
+            } else {
+#pragma unroll
+                for (int i = 15; i >= 0; --i) first = acc[ct][i] * scale == mx ? ct * 16 + i : first;
+            }
+        }
+        mi = first < NREG ? wave_c0 + (first >> 4) * 32 + (first & 3) + 8 * ((first >> 2) & 3) + 4 * h : 0x7fffffff;
+    }
     {
         float omx = __shfl_xor(mx, 32);
         int omi = __shfl_xor(mi, 32);
@@ -246,20 +290,54 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
         }
         __syncthreads();
     }
-
-    float se = 0.f, serw = 0.f, zy = 0.f, rawy = 0.f;
+    STAMP(3);
+    // label logit: register number = (tile, i) with i&3 = row&3, i>>2 = row>>3, h = (row>>2)&1
+    const int rel = lab - wave_c0;
+    const bool mine = rel >= 0 && rel < CTW * 32 && ((rel >> 2) & 1) == h;
+    float rawy;
+    {
+        const int reg = (rel & 3) | ((rel >> 3) & 3) << 2 | (rel >> 5) << 4;
+        float t[NREG];
 #pragma unroll
-    for (int ct = 0; ct < CTW; ++ct)
+        for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
-            float raw = acc[ct][i];
-            float e = cls < C ? expf(raw * scale - mx) : 0.f;
-            se += e;
-            serw += e * raw;
-            if (cls == lab) { zy = raw * scale; rawy = raw; }
-            acc[ct][i] = e;                 // keep exp() for the dZ pass
+            for (int i = 0; i < 16; ++i) t[ct * 16 + i] = acc[ct][i];
+#pragma unroll
+        for (int bit = 0, n = NREG; n > 1; ++bit, n >>= 1) {
+            const bool up = (reg >> bit) & 1;
+#pragma unroll
+            for (int j = 0; j < n / 2; ++j) t[j] = up ? t[2 * j + 1] : t[2 * j];
         }
+        rawy = mine ? t[0] : 0.f;
+    }
+    const float rawy_lane = rawy;                           // this lane's own label logit (or 0)
+    // e = exp(raw * scale - max), kept in the accumulators for the dZ pass
+    float se = 0.f, serw = 0.f;
+    const float nmx = -mx;
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) {
+        const int cbase = wave_c0 + ct * 32;
+        if (cbase + 32 > C) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float raw = acc[ct][i];
+                const float e = cbase + acc_row(i, h) < C ? __builtin_amdgcn_exp2f(__builtin_fmaf(raw, scale, nmx) * LOG2E) : 0.f;
+                se += e;
+                serw = __builtin_fmaf(e, cbase + acc_row(i, h) < C ? raw : 0.f, serw);
+                acc[ct][i] = e;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float raw = acc[ct][i];
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(raw, scale, nmx) * LOG2E);
+                se += e;
+                serw = __builtin_fmaf(e, raw, serw);
+                acc[ct][i] = e;
+            }
+        }
+    }
+    float zy = rawy * scale;
     se += __shfl_xor(se, 32);
     serw += __shfl_xor(serw, 32);
     zy += __shfl_xor(zy, 32);
@@ -277,22 +355,36 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
             se += d[0]; serw += d[1]; zy += d[2]; rawy += d[3];
         }
     }
+    STAMP(4);
 
     if (a.dzt != nullptr) {       // rows past the segment write zeros: the dW GEMM needs no masking of dZ^T
         const float coef = valid ? sg.w_over_rows * scale : 0.f;
         const float inv = 1.f / se;
-        float* dst = a.dzt + sg.col0 + r;
+        // every wave has passed the last barrier of the main loop (and the exchanges above): the tile buffers are free.
+        // Wave-private staging tile [CTW*32 class rows][32 samples] fp32, no padding: the ds_write_b32 of a register is 32
+        // consecutive floats per lane half, the ds_read_b128 of 8 rows x 8 quads is conflict-free in the 16-lane groups
+        float* stg = smem + wave * (CTW * 32 * 32);
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int cls = (wc * CTW + ct) * 32 + acc_row(i, h);
-                if (cls < C) {
-                    float p = acc[ct][i] * inv;
-                    store_out_f32(dst + (size_t)cls * a.ldz, (p - (cls == lab ? 1.f : 0.f)) * coef, a.plain);
-                }
-            }
+            for (int i = 0; i < 16; ++i) stg[(ct * 32 + acc_row(i, h)) * 32 + l31] = (acc[ct][i] * inv) * coef;
+        if (mine) {                                          // the one-hot term, by the lane that owns the label's logit
+            const float ey = __builtin_amdgcn_exp2f(__builtin_fmaf(rawy_lane, scale, nmx) * LOG2E);
+            stg[rel * 32 + l31] = (ey * inv - 1.f) * coef;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* dst = a.dzt + sg.col0 + row0 + ws * 32 + 4 * (lane & 7);
+#pragma unroll
+        for (int it = 0; it < CTW * 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int cls = wave_c0 + row;
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(stg + row * 32 + 4 * (lane & 7));
+            if (cls < C) store_out_f32x4(dst + (size_t)cls * a.ldz, v, a.plain);
+        }
     }
+    STAMP(5);
 
     // per-block sums of loss / top-1 / d(scale), taken once per sample (wc==0, h==0 lanes)
     float vl = 0.f, vc = 0.f, vg = 0.f;
@@ -321,6 +413,8 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
         float* o = a.partials + (size_t)blockIdx.x * 4;
         o[0] = l; o[1] = c; o[2] = g; o[3] = 0.f;
     }
+    STAMP(6);
+#undef STAMP
 }
 
 // --------------------------------------------------------------------------- //
@@ -1140,20 +1234,21 @@ int umlh_f32_fwd_config(int C, int* ctw, int* wc) {
 
 static size_t fwd_smem_bytes(int ctw, int wc) {
     int ws = 8 / wc, cpad = 32 * ctw * wc, ts = 32 * ws;
-    return sizeof(float) * (size_t)(2 * KT * (cpad + 4 + ts + 4) + wc * ts * 4 + ws * 4 + 16);
+    size_t tile = (size_t)2 * KT * (cpad + 4 + ts + 4), stg = (size_t)8 * ctw * 32 * 32;   // (the epilogue's dZ staging aliases the tile buffers)
+    return sizeof(float) * ((tile > stg ? tile : stg) + (size_t)(wc * ts * 4 + ws * 4 + 16));
 }
 
 #define FWD_CASE_F(CT, W, F)                                                                        \
     if (ctw == CT && wc == W && fast == F) {                                                        \
         size_t sm = fwd_smem_bytes(CT, W);                                                          \
-        static unsigned long long attr_done = 0;           /* bit d: done on device d (the attribute is per device) */ \
+        static std::atomic<unsigned long long> attr_done{0};  /* bit d: done on device d (the attribute is per device) */ \
         int dev_ = 0;                                                                               \
         (void)hipGetDevice(&dev_);                                                                  \
-        if (!((attr_done >> (dev_ & 63)) & 1ULL)) {                                                 \
+        if (!((attr_done.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ULL)) {                 \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_ce_f32<CT, W, F>),\
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);\
             if (e != hipSuccess) return (int)e;                                                     \
-            attr_done |= 1ULL << (dev_ & 63);                                                       \
+            attr_done.fetch_or(1ULL << (dev_ & 63), std::memory_order_release);                     \
         }                                                                                           \
         FwdArgs c_ = *a; c_.plain = umlh_plain_stores();                                            \
         hipLaunchKernelGGL((fwd_ce_f32<CT, W, F>), dim3(grid), dim3(512), sm, stream, c_);          \
@@ -1187,12 +1282,12 @@ int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStrea
     if (g->M <= 0 || g->N <= 0) return 0;
     if (dw_f32_applies(g, ta, tb)) {
         int dev = 0;
-        static unsigned attr_done = 0;                    // per-device bit: the kernel's dynamic LDS limit is raised once
+        static std::atomic<unsigned long long> attr_done{0};   // per-device bit: the kernel's dynamic LDS limit is raised once
         if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
-        if (dev < 32 && !(attr_done & (1u << dev))) {
+        if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ULL)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM);
             if (e != hipSuccess) return (int)e;
-            attr_done |= 1u << dev;
+            attr_done.fetch_or(1ULL << (dev & 63), std::memory_order_release);
         }
         GemmArgs a = *g;
         a.slab_count = splits;

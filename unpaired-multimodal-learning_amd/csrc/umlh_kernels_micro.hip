@@ -22,6 +22,7 @@
 // All workgroups of a launch must be co-resident (spin waits): the host launches at most one workgroup per CU and
 // chains micro launches of one process on one device; every spin is bounded and reports through a status word.
 #include "umlh_common.h"
+#include <atomic>
 #include "umlh_micro.h"
 #include <type_traits>
 
@@ -757,14 +758,14 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
 template <int NCH, int CW, bool BF>
 int launch_one(const UmlhMicroHead* heads, int n_heads, int n_steps, int grid, hipStream_t st) {
     using K = MicroCfg<NCH, CW, BF && CW == 128 && NCH <= 5>;
-    static unsigned long long attr_done = 0;               // bit d: done on device d
+    static std::atomic<unsigned long long> attr_done{0};   // bit d: done on device d
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_done >> (dev & 63)) & 1ULL)) {
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ULL)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&micro_steps_kernel<NCH, CW, BF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
         if (e != hipSuccess) return (int)e;
-        attr_done |= 1ULL << (dev & 63);
+        attr_done.fetch_or(1ULL << (dev & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL((micro_steps_kernel<NCH, CW, BF>), dim3(grid), dim3(256), K::SMEM, st, heads, n_heads, n_steps);
     return (int)hipGetLastError();
