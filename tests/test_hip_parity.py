@@ -389,3 +389,52 @@ def test_head_with_bias_matches_reference(tag, kind, precision):
     # the optimizer's state is visible under the reference's parameter names
     st = opt.state[m.head.bias]
     assert any(v.shape == (C,) for v in st.values())
+
+
+_F32_FWD_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import umlh
+rng = np.random.default_rng(17)
+out = []
+for (d, C, n, bi, bt, proj) in ((512, 1000, 3000, 1024, 700, 0), (64, 100, 900, 300, 257, 0), (96, 37, 500, 40, 90, 0), (128, 300, 800, 256, 100, 64)):
+    d_img = proj if proj else d
+    x = rng.standard_normal((n, d_img)).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    xt = rng.standard_normal((n, d)).astype(np.float32); xt /= np.linalg.norm(xt, axis=1, keepdims=True)
+    y = rng.integers(0, C, n)
+    w = rng.standard_normal((C, d)).astype(np.float32); w /= np.linalg.norm(w, axis=1, keepdims=True)
+    e = umlh.HeadEngine(d_img, d, C, has_proj=bool(proj), optimizer="adamw", weight_decay=0.01, max_rows_img=1024, max_rows_txt=1024,
+                        precision="fp32", device="cuda:0")
+    e.w_head.copy_(torch.from_numpy(w)); e.scales.fill_(50.0)
+    if proj: e.w_proj.normal_(0, 0.1, generator=torch.Generator(device="cuda").manual_seed(3))
+    X = torch.from_numpy(x).cuda(); XT = torch.from_numpy(xt).cuda(); Y = torch.from_numpy(y).cuda()
+    g = torch.Generator().manual_seed(2)
+    sc = torch.zeros(8, umlh.N_SCALARS, device="cuda")
+    for k in range(8):
+        ii = torch.randint(0, n, (bi if k % 3 else bi // 2 + 1,), generator=g).cuda(); ti = torch.randint(0, n, (bt,), generator=g).cuda()
+        e.train_step(umlh.RowBatch(X, Y, ii), umlh.RowBatch(XT, Y, ti) if k != 5 else None, lr=1e-2, step=k + 1, scalars_out=sc[k])
+    ev = e.eval_batch(umlh.RowBatch(X, Y, torch.arange(0, min(n, 1024)).cuda()))
+    torch.cuda.synchronize()
+    out.append(hashlib.sha256(e.w_head.cpu().numpy().tobytes() + e.v_head.cpu().numpy().tobytes() + sc.cpu().numpy().tobytes()
+                              + np.asarray([float(v) for v in ev], dtype=np.float64).tobytes()).hexdigest()[:16])
+print("DIGEST", *out)
+"""
+
+
+@pytest.mark.gpu
+def test_fp32_forward_streamed_weights_equals_lds_staged_forward_bit_for_bit(tmp_path):
+    """Round 3: fwd_ce_f32 streams W from a fragment-major fp32 shadow (kept current by the update kernel) instead of staging it
+    through LDS chunk by chunk.  Same products in the same order: eight AdamW steps (changing batches, a text-less step, the
+    2-layer head, a K that needs several X blocks' worth of chunks) and an evaluation end in bit-identical weights, moments and
+    scalars under UMLH_F32_FWD=1 (LDS-staged kernel) and the default.  The switch is read once per process: child processes."""
+    import os, subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unpaired-multimodal-learning_amd")
+    script = tmp_path / "f32_fwd_case.py"
+    script.write_text(_F32_FWD_SCRIPT)
+    digests = {}
+    for mode in ("1", "2"):
+        env = dict(os.environ, UMLH_F32_FWD=mode)
+        r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[mode] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1]
+    assert digests["1"] == digests["2"]

@@ -26,9 +26,10 @@ int umlh_launch_reduce_update(int mode, const float* slabs, int n_slabs, long lo
                               float* grad_out, float* p, float* m, float* v, const OptArgs* o, long long frozen_lo,
                               long long frozen_hi, hipStream_t stream);
 int umlh_launch_finalize(const FinalizeArgs* f, hipStream_t stream);
+int umlh_launch_w_shadow32(const float* w, float* dst, int C, int K, int cpad, hipStream_t stream);
 int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
                           float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out,
-                          const DiagArgs* dg, hipStream_t stream);
+                          const DiagArgs* dg, float* shadow32, hipStream_t stream);
 int umlh_launch_zero_shot(const float* feats, const int64_t* labels, long long n, int d, int C, float* w,
                           hipStream_t stream);
 int umlh_launch_to_bf16(const float* src, void* dst, long long n, hipStream_t stream);
@@ -78,7 +79,7 @@ static int fail(int code, const char* fmt, ...) {
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
 
 struct Layout {                 // workspace partition, in floats from the base
-    long long dzt, h, dht, slabs_head, slabs_proj, partials, diag_part, grads, w16, iota, zeros, dbg, wpt16, wht16, xch, fuse_flags, total;
+    long long dzt, h, dht, slabs_head, slabs_proj, partials, diag_part, grads, w16, iota, zeros, dbg, wpt16, wht16, xch, fuse_flags, w32s, total;
     long long ctl_tasks;        // one-launch step: task capacity of the control region at fuse_flags: [cap] u64 done, [cap] u32 claim, [16] u32 status
     int fwd_nq;                 // bf16 2-D forward (fwd_ce_bf16_q): class groups per row tile, 0 = the 1-D kernel
     long long mc_flags, mc_xchg, mc_ext, mc_tab, mc_desc;   // micro-step region (umlh_kernels_micro.hip); mc_flags = 0: unsupported shape
@@ -179,6 +180,12 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
             L.fwd_nq = nq;
             L.xch = take(2LL * (L.ldz / 128 + 2) * nq * 4 * 128);      // 8-byte granules
         }
+    }
+    // fp32 mode: fragment-major fp32 shadow of w_head for the streamed forward (fwd_ce_f32 MODE 2): [K/16][cpad/32][64][8] floats
+    L.w32s = 0;
+    if (c.precision == UMLH_PREC_FP32 && c.d_shared % 32 == 0) {
+        int ctw = 0, wc = 0;
+        if (umlh_f32_fwd_config(c.num_classes, &ctw, &wc) > 0) L.w32s = take((long long)c.d_shared * 32 * ctw * wc);
     }
     // one-launch step (step_bf16): per task one done granule (u64) and one claim word (u32), then the status words
     L.ctl_tasks = L.max_blocks + 4096 + L.n_head / 2048 + 8;
@@ -1082,7 +1089,16 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     fa.dzt = want_grad ? dzt : nullptr; fa.ldz = L.ldz;
     fa.partials = ws(h, L.partials);
     fa.row_stats = h->row_stats;
-    fa.stamps = h->dbg_fwd == 9 ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
+    fa.stamps = (h->dbg_fwd == 9 || h->dbg_fwd >= 20) ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
+    fa.dbg = h->dbg_fwd;
+    if (L.w32s) {
+        // refreshed here unless the previous step of the same umlh_train_steps call (or the data-parallel update) just wrote
+        // it from its update kernel (between calls the caller may have rewritten w_head)
+        if (!h->shadow_fresh)
+            HIPCHK(umlh_launch_w_shadow32(h->buf.w_head, ws(h, L.w32s), c.num_classes, c.d_shared, 32 * h->ctw * h->wc, st), "w_shadow32");
+        h->shadow_fresh = false;
+        fa.Ws = ws(h, L.w32s);
+    }
     HIPCHK(umlh_f32_launch_fwd(&fa, h->ctw, h->wc, nb0 + nb1, st), "fwd_ce");
     mark(h, 2, st);
     if (!want_grad) return UMLH_OK;
@@ -1227,8 +1243,8 @@ static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_
         const bool bf = c.precision == UMLH_PREC_BF16;
         HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, h->L.n_head, c.num_classes, c.d_shared, h->buf.w_head,
                                      h->buf.m_head, h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr,
-                                     32 * h->ctw * h->wc, &f, nullptr, &dg, st), "head step");
-        h->shadow_fresh = bf && keep_shadow;
+                                     32 * h->ctw * h->wc, &f, nullptr, &dg, h->L.w32s ? ws(h, h->L.w32s) : nullptr, st), "head step");
+        h->shadow_fresh = (bf || h->L.w32s) && keep_shadow;
     } else {
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
         HIPCHK(umlh_launch_reduce_update(1, ws(h, h->L.slabs_head), sh, h->L.n_head, h->L.n_head, nullptr,
@@ -1649,12 +1665,12 @@ static int dp_reduce_head(umlh_handle_t h, const umlh_batch_t* img, const umlh_b
         f2.partials = nullptr;                           // the step scalars are formed once (first launch)
         DiagArgs none; none.dst = nullptr; none.n_slabs_img = si; none.inv_w0 = none.inv_w1 = 0.f; none.part = nullptr; none.ticket = nullptr;
         if (si > 0) HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), si, nh, h->cfg.num_classes, h->cfg.d_shared, nullptr, nullptr,
-                                                 nullptr, &o, nullptr, 32 * h->ctw * h->wc, &f, grads, &none, st), "reduce head (image rows)");
+                                                 nullptr, &o, nullptr, 32 * h->ctw * h->wc, &f, grads, &none, nullptr, st), "reduce head (image rows)");
         else HIPCHK((int)hipMemsetAsync(grads, 0, sizeof(float) * nh, st), "zero image gradient");
         none.n_slabs_img = 0;
         if (sh - si > 0) HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head) + (size_t)si * nh, sh - si, nh, h->cfg.num_classes, h->cfg.d_shared,
                                                       nullptr, nullptr, nullptr, &o, nullptr, 32 * h->ctw * h->wc, si > 0 ? &f2 : &f, grads + nh,
-                                                      &none, st), "reduce head (text rows)");
+                                                      &none, nullptr, st), "reduce head (text rows)");
         else HIPCHK((int)hipMemsetAsync(grads + nh, 0, sizeof(float) * nh, st), "zero text gradient");
         return UMLH_OK;
     }
@@ -1664,7 +1680,7 @@ static int dp_reduce_head(umlh_handle_t h, const umlh_batch_t* img, const umlh_b
         DiagArgs order; order.dst = nullptr; order.n_slabs_img = h->n_slabs_img < sh ? h->n_slabs_img : sh;
         order.inv_w0 = order.inv_w1 = 0.f; order.part = nullptr; order.ticket = nullptr;
         HIPCHK(umlh_launch_head_step(ws(h, h->L.slabs_head), sh, nh, h->cfg.num_classes, h->cfg.d_shared, nullptr, nullptr, nullptr, &o,
-                                     nullptr, 32 * h->ctw * h->wc, &f, grads, &order, st), "reduce head");
+                                     nullptr, 32 * h->ctw * h->wc, &f, grads, &order, nullptr, st), "reduce head");
     } else {
         HIPCHK(umlh_launch_finalize(&f, st), "finalize");
         HIPCHK(umlh_launch_reduce_update(0, ws(h, h->L.slabs_head), sh, nh, nh, grads, nullptr, nullptr, nullptr, &o, 0, 0, st), "reduce head");
@@ -1790,8 +1806,8 @@ static int apply_update_impl(umlh_handle_t h, const umlh_hyper_t* hy, float* sca
         }
         HIPCHK(umlh_launch_head_step(grads, h->dp_diag ? 2 : 1, h->L.n_head, h->cfg.num_classes, h->cfg.d_shared, h->buf.w_head,
                                      h->buf.m_head, h->buf.v_head, &o, bf ? ws(h, h->L.w16) : nullptr, 32 * h->ctw * h->wc, &f, nullptr,
-                                     h->dp_diag ? &dg : nullptr, st), "update head");
-        h->shadow_fresh = bf;              // the next umlh_grad_step may trust it (see umlh_grad_step)
+                                     h->dp_diag ? &dg : nullptr, h->L.w32s ? ws(h, h->L.w32s) : nullptr, st), "update head");
+        h->shadow_fresh = bf || h->L.w32s;              // the next umlh_grad_step may trust it (see umlh_grad_step)
     } else {
         HIPCHK(umlh_launch_reduce_update(1, grads, 1, h->L.n_head, h->L.n_head, nullptr, h->buf.w_head, h->buf.m_head,
                                          h->buf.v_head, &o, 0, 0, st), "update head");

@@ -63,6 +63,8 @@ struct FwdArgs {
     int   plain;                 // 1 = plain stores for dZ^T (default 0: write-through, see store_wt_f32)
     float* row_stats;            // optional per-row {CE, top-1 correct} of segment 0 then segment 1 (whole-table evaluation)
     unsigned long long* stamps;  // diagnostics (UMLH_DBG_FWD=9): [grid][8 waves][8] cycle stamps, else NULL
+    const float* Ws;             // fp32 fragment-major shadow of W (w_shadow32_kernel), current; NULL = stage W through LDS
+    int   dbg;                   // timing-only ablations of the streamed main loop (analysis build -DUMLH_ABLATIONS only): 21 no W refills, 22 no B reads, 23 both
 };
 
 // Elementwise tail of a dense layer of the MultiBench encoder, applied to v = alpha * sum (element (m, n), flat index

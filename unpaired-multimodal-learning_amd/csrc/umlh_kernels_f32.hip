@@ -16,6 +16,13 @@
 #include <cstdlib>
 #include <atomic>
 
+// timing-only ablations exist for kernel analysis and are compiled in only with -DUMLH_ABLATIONS (see umlh_kernels_bf16.hip)
+#ifdef UMLH_ABLATIONS
+#define UMLH_ABL(cond) (cond)
+#else
+#define UMLH_ABL(cond) (false)
+#endif
+
 // --------------------------------------------------------------------------- //
 // staging helpers: global -> registers -> LDS, k-major LDS tiles [KT][LD]
 // --------------------------------------------------------------------------- //
@@ -44,8 +51,16 @@ __device__ __forceinline__ f32x4v load4_guard(const float* p, int lim, bool vec_
 // FAST (host-checked: K % 16 == 0, 16-B aligned operands): every load is an unconditional 16-B
 // vector load from a clamped address, so the compiler keeps counted vmcnt waits instead of
 // branching around guarded loads (out-of-range rows load a valid row; their results are masked).
-template <int CTW, int WC, bool FAST>
+// MODE 0: guarded loads (any K / alignment).  MODE 1 ("FAST"): LDS-staged W and X chunks, unconditional 16-B loads.
+// MODE 2 (round 3): W is NOT staged at all -- it streams global -> registers from a fragment-major fp32 shadow (see
+// w_shadow32_kernel) through a 2-chunk register ring, the block's X rows are resident in LDS for a K-block of 64 KB, and the
+// main loop has no barrier inside a K-block: with the 64-cycle fp32 MFMA the two waves of a SIMD keep the matrix pipe busy
+// while their rings refill (the stream is 16 B/clk/CU, a quarter of what the bf16 forward pulls).  MODE 1 spent 28 % of its
+// main loop between chunks (64 KB of W through registers into LDS and a barrier per 16 k: 5.67k cycles per chunk for 4.1k of
+// MFMA; scripts/fwd32_stamps.py).  Same products in the same order as MODE 1: bit-identical results.
+template <int CTW, int WC, int MODE>
 __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
+    constexpr bool FAST = MODE >= 1;
     constexpr int WS = 8 / WC;
     constexpr int CPAD = 32 * CTW * WC;
     constexpr int TS = 32 * WS;
@@ -59,7 +74,9 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     constexpr int BUF = KT * (LDW + LDX);
     float* Ws0 = smem;                    // [2][KT][LDW] then [KT][LDX]
     constexpr int STG = 8 * CTW * 32 * 32;                                  // epilogue: dZ staging, 8 waves x [CTW*32][32] floats (aliases the tile buffers)
-    constexpr int TILE = 2 * BUF > STG ? 2 * BUF : STG;
+    constexpr int XT2 = MODE == 2 ? TS * (16384 / TS + 4) : 0;              // MODE 2: the resident X block
+    constexpr int TILE0 = 2 * BUF > STG ? 2 * BUF : STG;
+    constexpr int TILE = TILE0 > XT2 ? TILE0 : XT2;
     float* red = smem + TILE;             // [WC][TS][4]
     float* red2 = red + WC * TS * 4;      // [WS][4]
 
@@ -75,29 +92,6 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     const bool vecW = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
     const bool vecX = (sg.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.feats) & 15) == 0);
 
-    // per-thread source rows (hoisted out of the K loop)
-    const float* wsrc[NPW];
-    const float* xsrc[NPX];
-#pragma unroll
-    for (int q = 0; q < NPW; ++q) {
-        int p = tid + 512 * q, cls = p >> 2;
-        if (FAST) wsrc[q] = a.W + (size_t)min(cls, C - 1) * K;        // rows >= C: logits masked to -inf below
-        else wsrc[q] = (p < CPAD * 4 && cls < C) ? a.W + (size_t)cls * K : nullptr;
-    }
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) {
-        int p = tid + 512 * q, smp = p >> 2, r = row0 + smp;
-        const float* s = nullptr;
-        if (FAST) {
-            int rc = min(r, sg.rows - 1);                              // rows past the segment: coef = 0 below
-            int64_t rid = sg.feat_index ? sg.feat_index[rc] : (int64_t)rc;
-            s = sg.feats + (size_t)rid * sg.ld;
-        } else if (p < TS * 4 && r < sg.rows) {
-            int64_t rid = sg.feat_index ? sg.feat_index[r] : (int64_t)r;
-            s = sg.feats + (size_t)rid * sg.ld;
-        }
-        xsrc[q] = s;
-    }
     // label of this lane's sample: dependent loads issued before the main loop hides them
     int lab_pre;
     {
@@ -111,113 +105,210 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
 
-    f32x4v wreg[NPW], xreg[NPX];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < NPW; ++q) {
-            int g = (tid + 512 * q) & 3;
-            int k = k0 + 4 * g;
-            if (FAST) wreg[q] = *reinterpret_cast<const f32x4v*>(wsrc[q] + k);
-            else wreg[q] = wsrc[q] ? load4_guard(wsrc[q] + k, K - k, vecW) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int q = 0; q < NPX; ++q) {
-            int g = (tid + 512 * q) & 3;
-            int k = k0 + 4 * g;
-            if (FAST) xreg[q] = *reinterpret_cast<const f32x4v*>(xsrc[q] + k);
-            else xreg[q] = xsrc[q] ? load4_guard(xsrc[q] + k, K - k, vecX) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    // FAST: the LDS tiles are [row][16 k] (row = class / sample, 64 B) with the four 16-B slots of a row XOR-swizzled by
-    // (row >> 2) & 3: the 16-B pieces go to LDS as they come from memory (no transposing scalar stores), and the eight
-    // k-steps of a chunk of one MFMA operand are two ds_read_b128 (lane half h multiplies k = 8h .. 8h+7; the order of k
-    // inside a chunk is free as long as W and X agree) -- 10 LDS reads per 32 MFMAs instead of 40, 9 LDS stores per thread
-    // instead of 36.  The swizzle makes both access patterns conflict-free without padding (same 64 KB per W buffer).
-    auto lstore = [&](int buf) {
-        float* Ws = Ws0 + buf * BUF;
-        float* Xs = Ws + KT * LDW;
-#pragma unroll
-        for (int q = 0; q < NPW; ++q) {
-            int p = tid + 512 * q;
-            if (p < CPAD * 4) {
-                int cls = p >> 2, g = p & 3;
-                if (FAST) *reinterpret_cast<f32x4v*>(&Ws[cls * KT + 4 * (g ^ ((cls >> 2) & 3))]) = wreg[q];
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Ws[(4 * g + j) * LDW + cls] = wreg[q][j];
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NPX; ++q) {
-            int p = tid + 512 * q;
-            if (p < TS * 4) {
-                int smp = p >> 2, g = p & 3;
-                if (FAST) *reinterpret_cast<f32x4v*>(&Xs[smp * KT + 4 * (g ^ ((smp >> 2) & 3))]) = xreg[q];
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Xs[(4 * g + j) * LDX + smp] = xreg[q][j];
-                }
-            }
-        }
-    };
     // A wave whose 32 sample rows all lie past the segment (batch 32 in a 64-row block: the reference's
     // own batch sizes are 8-64) or whose class tiles all lie past C skips its MFMAs: fp32 MFMA issue
     // (64 cycles per 32x32x2) is what bounds a single-workgroup forward, and its SIMD partner then
     // runs alone.  Wave-uniform; the accumulators stay 0 and the epilogue masks them as before.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const bool wave_live = row0 + (wave_u / WC) * 32 < sg.rows && (wave_u % WC) * CTW * 32 < C;
-    auto compute = [&](int buf) {
-        const float* Ws = Ws0 + buf * BUF;
-        const float* Xs = Ws + KT * LDW;
-        if (!wave_live) return;                       // ONE wave-uniform branch per chunk: the MFMA loop itself stays branch-free
-        if (FAST) {
-            const int sw = (l31 >> 2) & 3;            // tile bases are multiples of 32: (row >> 2) & 3 == (l31 >> 2) & 3
-            const float* xr = Xs + (ws * 32 + l31) * KT;
-            f32x4v b[2], av[CTW][2];
-            b[0] = *reinterpret_cast<const f32x4v*>(xr + 4 * ((2 * h) ^ sw));
-            b[1] = *reinterpret_cast<const f32x4v*>(xr + 4 * ((2 * h + 1) ^ sw));
+    if constexpr (MODE == 2) {
+        constexpr int XK = 16384 / TS;                      // K-block of the X rows resident in LDS: TS x XK floats = 64 KB
+        constexpr int XLD = XK + 4;                         // row stride (floats): an odd multiple of 16 B -> the b128 reads of 16 rows hit 16 slots
+        constexpr int NPX2 = (TS * (XK / 4)) / 512;         // 16-B pieces of an X block per thread
+        constexpr int PD = 2;                               // chunks (16 k) of W fragments in flight per wave
+        float* Xt = smem;                                   // [TS][XLD]
+        const float* xs2[NPX2];
 #pragma unroll
-            for (int ct = 0; ct < CTW; ++ct) {
-                const float* wr = Ws + ((wc * CTW + ct) * 32 + l31) * KT;
-                av[ct][0] = *reinterpret_cast<const f32x4v*>(wr + 4 * ((2 * h) ^ sw));
-                av[ct][1] = *reinterpret_cast<const f32x4v*>(wr + 4 * ((2 * h + 1) ^ sw));
+        for (int q = 0; q < NPX2; ++q) {
+            const int pp = tid + 512 * q;
+            const int rc = min(row0 + pp / (XK / 4), sg.rows - 1);        // rows past the segment: coef = 0 below
+            const int64_t rid = sg.feat_index ? sg.feat_index[rc] : (int64_t)rc;
+            xs2[q] = sg.feats + (size_t)rid * sg.ld + 4 * (pp % (XK / 4));
+        }
+        // fragment (chunk c, class tile t): 64 lanes x 8 floats at Ws + ((c * CPAD/32 + t) * 64 + lane) * 8; lane (r, h) holds
+        // W[32 t + r][16 c + 8 h .. + 8): the A operands of its eight 32x32x2 steps of the chunk (k order inside a chunk is
+        // free as long as W and X agree; it is MODE 1's)
+        const float* wl = a.Ws + ((size_t)(wc * CTW) * 64 + lane) * 8;
+        const int nch = K / KT;                             // even (host-checked)
+        auto wfrag = [&](int c, int ct, int half) -> f32x4v {
+            return *reinterpret_cast<const f32x4v*>(wl + ((size_t)c * (CPAD / 32) + ct) * 512 + 4 * half);
+        };
+        f32x4v ring[PD][CTW][2];
+        if (wave_live) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d)
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) { ring[d][ct][0] = wfrag(min(d, nch - 1), ct, 0); ring[d][ct][1] = wfrag(min(d, nch - 1), ct, 1); }
+        }
+        STAMP(1);
+        for (int kb0 = 0; kb0 < K; kb0 += XK) {
+            const int kbw = min(XK, K - kb0);               // multiple of 32
+            f32x4v xr[NPX2];
+#pragma unroll
+            for (int q = 0; q < NPX2; ++q) {
+                const int col = 4 * ((tid + 512 * q) % (XK / 4));
+                xr[q] = *reinterpret_cast<const f32x4v*>(xs2[q] + kb0 + min(col, kbw - 4) - col);   // columns past the block: a valid piece nobody reads
             }
+            __syncthreads();                                // previous block fully consumed
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2)
+            for (int q = 0; q < NPX2; ++q) {
+                const int pp = tid + 512 * q;
+                *reinterpret_cast<f32x4v*>(Xt + (pp / (XK / 4)) * XLD + 4 * (pp % (XK / 4))) = xr[q];
+            }
+            __syncthreads();
+            if (wave_live) {
+                const int c0 = kb0 / KT, ncb = kbw / KT;
+                const float* xrow = Xt + (ws * 32 + l31) * XLD + 8 * h;
+                for (int c = 0; c < ncb; c += PD) {
 #pragma unroll
-                for (int ct = 0; ct < CTW; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct][s2 >> 2][s2 & 3], b[s2 >> 2][s2 & 3], acc[ct], 0, 0, 0);
-            return;
+                    for (int d = 0; d < PD; ++d) {
+                        const int cb = UMLH_ABL(a.dbg == 22 || a.dbg == 23) ? 0 : c + d;
+                        const f32x4v b0 = *reinterpret_cast<const f32x4v*>(xrow + cb * KT);
+                        const f32x4v b1 = *reinterpret_cast<const f32x4v*>(xrow + cb * KT + 4);
+#pragma unroll
+                        for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                            for (int ct = 0; ct < CTW; ++ct)
+                                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d][ct][s2 >> 2][s2 & 3], (s2 < 4 ? b0 : b1)[s2 & 3], acc[ct], 0, 0, 0);
+                        const int nxt = UMLH_ABL(a.dbg == 21 || a.dbg == 23) ? 0 : min(c0 + c + d + PD, nch - 1);      // (past the end: a harmless re-load of the last chunk)
+#pragma unroll
+                        for (int ct = 0; ct < CTW; ++ct) { ring[d][ct][0] = wfrag(nxt, ct, 0); ring[d][ct][1] = wfrag(nxt, ct, 1); }
+                        // pin the emitted order per chunk: B reads, its MFMAs, then the slot's refill loads (left alone, hipcc sinks
+                        // every refill to the end of the loop body and the next iteration's first MFMA waits a full L2 round trip)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);            // B reads
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8 * CTW, 0);      // MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x020, 2 * CTW, 0);      // VMEM reads
+                    }
+                }
+            }
+        }
+        __syncthreads();                                    // the epilogue's staging aliases the X block
+    } else {
+    // per-thread source rows (hoisted out of the K loop)
+        const float* wsrc[NPW];
+        const float* xsrc[NPX];
+#pragma unroll
+        for (int q = 0; q < NPW; ++q) {
+            int p = tid + 512 * q, cls = p >> 2;
+            if (FAST) wsrc[q] = a.W + (size_t)min(cls, C - 1) * K;        // rows >= C: logits masked to -inf below
+            else wsrc[q] = (p < CPAD * 4 && cls < C) ? a.W + (size_t)cls * K : nullptr;
         }
 #pragma unroll
-        for (int kk = 0; kk < KT / 2; ++kk) {
-            const int krow = 2 * kk + h;
-            const float b = Xs[krow * LDX + ws * 32 + l31];
-#pragma unroll
-            for (int ct = 0; ct < CTW; ++ct) {
-                const float av = Ws[krow * LDW + (wc * CTW + ct) * 32 + l31];
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[ct], 0, 0, 0);
+        for (int q = 0; q < NPX; ++q) {
+            int p = tid + 512 * q, smp = p >> 2, r = row0 + smp;
+            const float* s = nullptr;
+            if (FAST) {
+                int rc = min(r, sg.rows - 1);                              // rows past the segment: coef = 0 below
+                int64_t rid = sg.feat_index ? sg.feat_index[rc] : (int64_t)rc;
+                s = sg.feats + (size_t)rid * sg.ld;
+            } else if (p < TS * 4 && r < sg.rows) {
+                int64_t rid = sg.feat_index ? sg.feat_index[r] : (int64_t)r;
+                s = sg.feats + (size_t)rid * sg.ld;
             }
+            xsrc[q] = s;
         }
-    };
+    f32x4v wreg[NPW], xreg[NPX];
+        auto gload = [&](int k0) {
+#pragma unroll
+            for (int q = 0; q < NPW; ++q) {
+                int g = (tid + 512 * q) & 3;
+                int k = k0 + 4 * g;
+                if (FAST) wreg[q] = *reinterpret_cast<const f32x4v*>(wsrc[q] + k);
+                else wreg[q] = wsrc[q] ? load4_guard(wsrc[q] + k, K - k, vecW) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < NPX; ++q) {
+                int g = (tid + 512 * q) & 3;
+                int k = k0 + 4 * g;
+                if (FAST) xreg[q] = *reinterpret_cast<const f32x4v*>(xsrc[q] + k);
+                else xreg[q] = xsrc[q] ? load4_guard(xsrc[q] + k, K - k, vecX) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        // FAST: the LDS tiles are [row][16 k] (row = class / sample, 64 B) with the four 16-B slots of a row XOR-swizzled by
+        // (row >> 2) & 3: the 16-B pieces go to LDS as they come from memory (no transposing scalar stores), and the eight
+        // k-steps of a chunk of one MFMA operand are two ds_read_b128 (lane half h multiplies k = 8h .. 8h+7; the order of k
+        // inside a chunk is free as long as W and X agree) -- 10 LDS reads per 32 MFMAs instead of 40, 9 LDS stores per thread
+        // instead of 36.  The swizzle makes both access patterns conflict-free without padding (same 64 KB per W buffer).
+        auto lstore = [&](int buf) {
+            float* Ws = Ws0 + buf * BUF;
+            float* Xs = Ws + KT * LDW;
+#pragma unroll
+            for (int q = 0; q < NPW; ++q) {
+                int p = tid + 512 * q;
+                if (p < CPAD * 4) {
+                    int cls = p >> 2, g = p & 3;
+                    if (FAST) *reinterpret_cast<f32x4v*>(&Ws[cls * KT + 4 * (g ^ ((cls >> 2) & 3))]) = wreg[q];
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Ws[(4 * g + j) * LDW + cls] = wreg[q][j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NPX; ++q) {
+                int p = tid + 512 * q;
+                if (p < TS * 4) {
+                    int smp = p >> 2, g = p & 3;
+                    if (FAST) *reinterpret_cast<f32x4v*>(&Xs[smp * KT + 4 * (g ^ ((smp >> 2) & 3))]) = xreg[q];
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Xs[(4 * g + j) * LDX + smp] = xreg[q][j];
+                    }
+                }
+            }
+        };
+        auto compute = [&](int buf) {
+            const float* Ws = Ws0 + buf * BUF;
+            const float* Xs = Ws + KT * LDW;
+            if (!wave_live) return;                       // ONE wave-uniform branch per chunk: the MFMA loop itself stays branch-free
+            if (FAST) {
+                const int sw = (l31 >> 2) & 3;            // tile bases are multiples of 32: (row >> 2) & 3 == (l31 >> 2) & 3
+                const float* xr = Xs + (ws * 32 + l31) * KT;
+                f32x4v b[2], av[CTW][2];
+                b[0] = *reinterpret_cast<const f32x4v*>(xr + 4 * ((2 * h) ^ sw));
+                b[1] = *reinterpret_cast<const f32x4v*>(xr + 4 * ((2 * h + 1) ^ sw));
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) {
+                    const float* wr = Ws + ((wc * CTW + ct) * 32 + l31) * KT;
+                    av[ct][0] = *reinterpret_cast<const f32x4v*>(wr + 4 * ((2 * h) ^ sw));
+                    av[ct][1] = *reinterpret_cast<const f32x4v*>(wr + 4 * ((2 * h + 1) ^ sw));
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct][s2 >> 2][s2 & 3], b[s2 >> 2][s2 & 3], acc[ct], 0, 0, 0);
+                return;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KT / 2; ++kk) {
+                const int krow = 2 * kk + h;
+                const float b = Xs[krow * LDX + ws * 32 + l31];
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) {
+                    const float av = Ws[krow * LDW + (wc * CTW + ct) * 32 + l31];
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[ct], 0, 0, 0);
+                }
+            }
+        };
 
-    // chunk c lives in buffer c & 1; registers hold chunk c+1 while chunk c is computed
-    gload(0);
-    lstore(0);
-    if (FAST) gload(min(KT, K - KT)); else if (KT < K) gload(KT);
-    __syncthreads();
-    STAMP(1);
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += KT) {
-        if (k0 + KT < K) lstore(buf ^ 1);                // chunk c+1 -> the other buffer (its readers passed the last barrier)
-        if (FAST) gload(min(k0 + 2 * KT, K - KT));       // branch-free: tail prefetches re-load the last chunk
-        else if (k0 + 2 * KT < K) gload(k0 + 2 * KT);
-        compute(buf);
+        // chunk c lives in buffer c & 1; registers hold chunk c+1 while chunk c is computed
+        gload(0);
+        lstore(0);
+        if (FAST) gload(min(KT, K - KT)); else if (KT < K) gload(KT);
         __syncthreads();
-        buf ^= 1;
-    }
+        STAMP(1);
+        int buf = 0;
+        for (int k0 = 0; k0 < K; k0 += KT) {
+            if (k0 + KT < K) lstore(buf ^ 1);                // chunk c+1 -> the other buffer (its readers passed the last barrier)
+            if (FAST) gload(min(k0 + 2 * KT, K - KT));       // branch-free: tail prefetches re-load the last chunk
+            else if (k0 + 2 * KT < K) gload(k0 + 2 * KT);
+            compute(buf);
+            __syncthreads();
+            buf ^= 1;
+        }
 
+    }
     STAMP(2);
     // ---------------- epilogue: softmax cross entropy on the register tile ----------------
     // VALU-bound (16*CTW logits per lane, two waves per SIMD): round 3 rewrote it after the bf16 kernel's -- max by v_max3
@@ -1043,7 +1134,8 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                         int C, int K, float* __restrict__ p, float* __restrict__ m,
                                                         float* __restrict__ v, OptArgs o, unsigned short* __restrict__ shadow,
-                                                        int cpad, FinalizeArgs f, float* __restrict__ grad_out, DiagArgs dg) {
+                                                        int cpad, FinalizeArgs f, float* __restrict__ grad_out, DiagArgs dg,
+                                                        float* __restrict__ shadow32) {
     __shared__ float sh[6][256];
     if (blockIdx.x == gridDim.x - 1) { finalize_body<false>(f, sh); return; }
     const long long g4 = (long long)blockIdx.x * 256 + threadIdx.x;      // group of 4 consecutive k of one class row
@@ -1128,6 +1220,11 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
         const u32x2s w = {pack_bf16x2(p0[0], p0[1]), pack_bf16x2(p0[2], p0[3])};
         if (o.plain) *reinterpret_cast<u32x2s*>(shadow + piece * 8 + (k & 7)) = w;
         else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(shadow + piece * 8 + (k & 7)), "v"(w) : "memory");
+    }
+    if (shadow32 != nullptr) {             // fp32 fragment-major shadow of the new weights (w_shadow32_kernel's layout): 4 floats = half a lane slot
+        const int cls = (int)(i / K), k = (int)(i % K);
+        const long long piece = ((long long)(k >> 4) * (cpad / 32) + (cls >> 5)) * 64 + (cls & 31) + 32 * ((k >> 3) & 1);
+        store_out_f32x4(shadow32 + piece * 8 + (k & 7), p0, o.plain);
     }
 }
 
@@ -1215,9 +1312,34 @@ __global__ __launch_bounds__(256) void feistel_perm_kernel(long long n, unsigned
 }
 
 // --------------------------------------------------------------------------- //
+// fp32 head-weight shadow for fwd_ce_f32 MODE 2, MFMA-FRAGMENT-MAJOR: [K/16 chunk][CPAD/32 class tile][64 lanes][8 floats];
+// lane l = (r, h) of tile t, chunk c holds W[32 t + r][16 c + 8 h .. + 8): a wave fetches the A operands of a chunk of one
+// class tile with two fully coalesced 1-KiB loads straight into registers.  Class rows >= C are zero.  One thread per 16 B.
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void w_shadow32_kernel(const float* __restrict__ w, float* __restrict__ dst, int C, int K, int cpad) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int tiles = cpad / 32;
+    const long long total = (long long)(K / 16) * tiles * 128;
+    if (q >= total) return;
+    const int half = (int)(q & 1), lane = (int)((q >> 1) & 63);
+    const int tile = (int)((q >> 7) % tiles), c = (int)((q >> 7) / tiles);
+    const int cls = tile * 32 + (lane & 31);
+    f32x4v v = {0.f, 0.f, 0.f, 0.f};
+    if (cls < C) v = *reinterpret_cast<const f32x4v*>(w + (size_t)cls * K + c * 16 + 8 * (lane >> 5) + 4 * half);
+    *reinterpret_cast<f32x4v*>(dst + q * 4) = v;
+}
+
+// --------------------------------------------------------------------------- //
 // launchers (called from umlh_api.cpp)
 // --------------------------------------------------------------------------- //
 extern "C" {
+
+int umlh_launch_w_shadow32(const float* w, float* dst, int C, int K, int cpad, hipStream_t stream) {
+    if (K % 16 != 0 || cpad % 32 != 0) return (int)hipErrorInvalidValue;
+    const long long total = (long long)(K / 16) * (cpad / 32) * 128;
+    hipLaunchKernelGGL(w_shadow32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, dst, C, K, cpad);
+    return (int)hipGetLastError();
+}
 
 // fwd_ce configuration for a class count: WC waves along classes, CTW 32-class
 // tiles per wave.  Returns samples per block (TS) or 0 if C is unsupported.
@@ -1232,15 +1354,18 @@ int umlh_f32_fwd_config(int C, int* ctw, int* wc) {
     return 32 * (8 / w);
 }
 
-static size_t fwd_smem_bytes(int ctw, int wc) {
+static size_t fwd_smem_bytes(int ctw, int wc, int mode) {
     int ws = 8 / wc, cpad = 32 * ctw * wc, ts = 32 * ws;
     size_t tile = (size_t)2 * KT * (cpad + 4 + ts + 4), stg = (size_t)8 * ctw * 32 * 32;   // (the epilogue's dZ staging aliases the tile buffers)
-    return sizeof(float) * ((tile > stg ? tile : stg) + (size_t)(wc * ts * 4 + ws * 4 + 16));
+    size_t xt2 = mode == 2 ? (size_t)ts * (16384 / ts + 4) : 0;
+    if (stg > tile) tile = stg;
+    if (xt2 > tile) tile = xt2;
+    return sizeof(float) * (tile + (size_t)(wc * ts * 4 + ws * 4 + 16));
 }
 
 #define FWD_CASE_F(CT, W, F)                                                                        \
-    if (ctw == CT && wc == W && fast == F) {                                                        \
-        size_t sm = fwd_smem_bytes(CT, W);                                                          \
+    if (ctw == CT && wc == W && mode == F) {                                                        \
+        size_t sm = fwd_smem_bytes(CT, W, F);                                                       \
         static std::atomic<unsigned long long> attr_done{0};  /* bit d: done on device d (the attribute is per device) */ \
         int dev_ = 0;                                                                               \
         (void)hipGetDevice(&dev_);                                                                  \
@@ -1254,7 +1379,7 @@ static size_t fwd_smem_bytes(int ctw, int wc) {
         hipLaunchKernelGGL((fwd_ce_f32<CT, W, F>), dim3(grid), dim3(512), sm, stream, c_);          \
         return (int)hipGetLastError();                                                              \
     }
-#define FWD_CASE(CT, W) FWD_CASE_F(CT, W, true) FWD_CASE_F(CT, W, false)
+#define FWD_CASE(CT, W) FWD_CASE_F(CT, W, 2) FWD_CASE_F(CT, W, 1) FWD_CASE_F(CT, W, 0)
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1263,6 +1388,10 @@ int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t
     bool fast = a->K % KT == 0 && aligned16(a->W);
     for (int s = 0; s < 2; ++s)
         if (a->seg[s].rows > 0) fast = fast && a->seg[s].ld % 4 == 0 && aligned16(a->seg[s].feats);
+    // MODE 2 (W streamed from the fragment-major shadow): the caller keeps the shadow current (umlh_launch_w_shadow32 /
+    // the update kernel) and passes it in a->Ws; UMLH_F32_FWD=1 keeps the LDS-staged kernel for A/B timing
+    static const bool no_stream = [] { const char* e = getenv("UMLH_F32_FWD"); return e && atoi(e) == 1; }();
+    const int mode = !fast ? 0 : ((a->Ws != nullptr && a->K % (2 * KT) == 0 && !no_stream) ? 2 : 1);
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(1, 8) FWD_CASE(2, 8) FWD_CASE(4, 8)
     return (int)hipErrorInvalidValue;
 }
@@ -1362,7 +1491,7 @@ int umlh_launch_multi_opt(int n, float* const* p, const float* const* g, float* 
 
 int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride, int C, int K, float* p, float* m,
                           float* v, const OptArgs* o, void* shadow, int cpad, const FinalizeArgs* f, float* grad_out,
-                          const DiagArgs* dg, hipStream_t stream) {
+                          const DiagArgs* dg, float* shadow32, hipStream_t stream) {
     long long n4 = (long long)C * K / 4;
     int blocks = (int)((n4 + 255) / 256) + 1;                 // + the finalize block
     DiagArgs d;
@@ -1372,7 +1501,7 @@ int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride
     OptArgs oc = *o;
     oc.plain = umlh_plain_stores();
     hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, oc,
-                       (unsigned short*)shadow, cpad, *f, grad_out, d);
+                       (unsigned short*)shadow, cpad, *f, grad_out, d, shadow32);
     return (int)hipGetLastError();
 }
 
