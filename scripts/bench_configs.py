@@ -50,6 +50,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cfg3-bf16":      # single config, e.g. under rocprofv3
         run("cfg3 DINOv2-L + OpenLLaMA two-layer head, batch 4096+4096", 1024, 3200, 1000, 4096, True, "bf16", steps=40)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg3-fp32":
+        run("cfg3 DINOv2-L + OpenLLaMA two-layer head, batch 4096+4096", 1024, 3200, 1000, 4096, True, "fp32", steps=20)
+        sys.exit(0)
     run("cfg1 Caltech101-like linear head, batch 32+32", 512, 512, 100, 32, False, "fp32")
     run("cfg1 Caltech101-like linear head, batch 32+32", 512, 512, 100, 32, False, "bf16")
     run("cfg5 CLIP-L/14-like d=768 C=397, batch 32+32", 768, 768, 397, 32, False, "fp32")

@@ -1162,6 +1162,220 @@ __device__ __forceinline__ int dw_bf16_body(const DwArgsB& g, const int vbid, co
 #undef DSTAMP
 }
 
+// --------------------------------------------------------------------------- //
+// Round 3: the same tile (128 x 128, 8 waves of 64 x 32, 64 reduction rows per chunk) with BOTH operands staged by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write -- the ds_write_b128 stream, 13 cycles per wave-instruction, was
+// 416 of the old loop's ~1270 cycles per chunk, on top of 384 cycles of fragment reads for 512 cycles of MFMA).
+//   * three LDS stages of (16 KB dZ^T tile + 16 KB feature tile); a chunk's 32 one-KiB pieces are issued two chunks ahead,
+//     four per wave; ONE raw s_barrier per chunk behind a counted s_waitcnt vmcnt (the DMA of the chunk after next stays in
+//     flight across it); no ordinary global load inside the loop (row ids live in LDS), so hipcc inserts no vmcnt(0)
+//   * the LDS-DMA destination is lane-linear (wave-uniform base + 16 B x lane), so the bank swizzles sit on the per-lane
+//     SOURCE address and on the reads (guide rule 21):  dZ^T tile [128 rows][8 x 16 B]: 16-B column c of row r is stored at
+//     column c ^ ((r >> 1) & 7) -- the b128 fragment reads of 16 rows hit 16 different 16-B slots;  feature tile [64 k-rows]
+//     [16 x 16 B]: chunk ch of row r at ch ^ (((r & 3) << 2) | ((r >> 2) & 3)) -- the transposing reads (ds_read_b64_tr_b16)
+//     of 4 rows x 32 columns per half-wave are conflict-free (guide T10, image (b))
+//   * masked pieces (rows past the split, padding rows, columns past N) read a zero page through their per-lane source
+// GATED: as dw_bf16_body -- row ids and the feature tiles of the first two chunks are issued before the wait for the forward
+// tiles, the dZ^T pieces after it, with device-coherent (sc1) DMA loads.
+// --------------------------------------------------------------------------- //
+constexpr int DST = 2;                                  // LDS stages
+constexpr int DKB = 128;                                // reduction rows per chunk: the per-chunk chain (barrier, DMA issue, first fragment
+                                                        // latency) costs ~800 cycles whatever the chunk holds -- with 64 rows (512 cycles of MFMA)
+                                                        // it was 60 % of the loop (scripts/dw_stamps.py: 1355 cycles per chunk)
+constexpr int DA_BYTES = DBM * 2 * DKB, DF_BYTES = DKB * 256;
+constexpr int DSTAGE_BYTES = DA_BYTES + DF_BYTES;       // 64 KB
+constexpr int DW_DMA_LDS_BYTES = DST * DSTAGE_BYTES + DIDS * 4;
+
+template <int AM, int OM, bool GATED>
+__device__ __forceinline__ int dw_bf16_body_dma(const DwArgsB& g, const int vbid, const DwGate& gate, unsigned char* lds, int* sh_rc) {
+    int* ids = reinterpret_cast<int*>(lds + DST * DSTAGE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int nx = (g.N + DBN - 1) / DBN;
+    const int z = vbid % g.nsplit, t = vbid / g.nsplit;
+    const int m0 = (t / nx) * DBM, n0 = (t % nx) * DBN;
+    const int kb = z < g.nsplit1 ? z * g.k_chunk : g.k_switch + (z - g.nsplit1) * g.k_chunk;    // multiple of 64
+    const int ke = min(z < g.nsplit1 ? g.k_switch : g.K, kb + g.k_chunk);
+    const int nchunks = g.k_chunk / DKB;                // (k_chunk is a multiple of 256)
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#define DSTAMP(i) do { if (g.stamps && lane == 0) g.stamps[((size_t)vbid * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    DSTAMP(0);
+    if (GATED && gate.timeline && tid == 0) gate.timeline[(size_t)(gate.self_base + vbid) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- per-lane invariants of the pieces this wave issues: pieces wave + 8q (q = 0..3) of each tile ----
+    // dZ^T piece p = rows 4p .. 4p+3 of [128 rows][16 x 16 B]; lane -> row 4p + (lane >> 4), physical column lane & 15, logical
+    // column ^ (row & 15)  (row & 15 is the same for all four pieces of a wave)
+    const int a_r0 = 4 * wave + (lane >> 4);
+    const int a_c = (lane & 15) ^ (a_r0 & 15);                             // logical 16-B column = k offset 8 * a_c
+    const int mclamp = g.M - 1 - m0;                                       // rows >= M: garbage that is never stored
+    const u16* a_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = a_r0 + 32 * q;
+        // AM 0: column-chunk-major [K/64][lda][64]: the 128-wide chunk spans two 64-column chunks
+        if (AM == 0) a_src[q] = g.A + (size_t)(a_c >> 3) * g.lda * 64 + ((size_t)m0 + min(r, mclamp)) * 64 + 8 * (a_c & 7);
+        else a_src[q] = g.A + (size_t)g.a_rows[m0 + min(r, mclamp)] * g.lda + 8 * a_c;
+    }
+    // feature piece p = k-rows 4p .. 4p+3 of [128 k-rows][16 x 16 B]; lane -> row 4p + (lane >> 4), physical chunk lane & 15,
+    // logical chunk ^ swz(row), swz(r) = ((r & 3) << 2) | ((r >> 2) & 3)
+    const int f_r0 = 4 * wave + (lane >> 4);
+    const int f_ch = (lane & 15) ^ (((f_r0 & 3) << 2) | ((f_r0 >> 2) & 3));     // same for the four pieces of a wave
+    const int f_colraw = n0 + 8 * f_ch;
+    const bool f_colok = f_colraw < g.N;
+    const int f_colc = min(f_colraw, g.N - 8);
+    const int f_col = (f_colc >> 6) * g.bcs + (f_colc & 63);              // row-major rows: bcs = 64 -> col
+    auto stage_ptr = [&](int st) -> unsigned char* { return lds + st * DSTAGE_BYTES; };
+    auto issueA = [&](int c, int st) {
+        const int k0 = kb + c * DKB;
+        const size_t achunk = AM == 0 ? (size_t)(k0 >> 6) * g.lda * 64 : (size_t)k0;
+        const bool on = k0 + 8 * a_c < ke;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u16* sp = on ? a_src[q] + achunk : g.zeros;
+            // (the dZ^T pieces of a GATED launch were written through by forward tiles of the same launch: coherent loads)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(stage_ptr(st) + (wave + 8 * q) * 1024), 16, 0, GATED ? 16 : 0);
+        }
+    };
+    auto issueF = [&](int c, int st) {
+        const int k0 = kb + c * DKB;                    // the two 64-row halves of a chunk may lie in different modalities
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool seg2 = k0 + 32 * q >= g.k_switch;  // (k_switch is a multiple of 64: rows 32q .. 32q+31 lie on one side)
+            const u16* fb = seg2 ? g.B2 : g.B;
+            const int ld = seg2 ? g.ldb2 : g.ldb;
+            const int rid = ids[c * DKB + f_r0 + 32 * q];
+            const long long off = (long long)rid * ld + f_col;             // formed unconditionally: a select, not a branch, picks the source
+            const u16* sp = (rid != DMASK && f_colok) ? fb + off : g.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(stage_ptr(st) + DA_BYTES + (wave + 8 * q) * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses (LDS byte addresses in stage 0) ----
+    // A: row r = wm*64 + i*32 + l31, k-step s (0..7): logical column 2s + h, stored at column ^ (r & 15) = ^ (l31 & 15)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    unsigned a_ad[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) a_ad[s8] = lds0 + (unsigned)((wm * 64 + l31) * 256 + (((2 * s8 + h) ^ (l31 & 15)) << 4));
+    // F: k-row R = 16s + 8h + q4 (+ 4 for the upper half of the fragment); element column wn*32 + (g16 & 1)*16 + 4*p4, i.e.
+    // 16-B chunk ch = wn*4 + (g16 & 1)*2 + (p4 >> 1), 8-byte half p4 & 1; swz(R) = (q4 << 2) | ((2h + hi) & 3) for every s
+    const int f_chr = wn * 4 + (g16 & 1) * 2 + (p4 >> 1);
+    const unsigned lds_lo = lds0 + (unsigned)(DA_BYTES + (8 * h + q4) * 256 + ((f_chr ^ ((q4 << 2) | ((2 * h) & 3))) << 4) + 8 * (p4 & 1));
+    const unsigned lds_hi = lds0 + (unsigned)(DA_BYTES + (8 * h + q4 + 4) * 256 + ((f_chr ^ ((q4 << 2) | ((2 * h + 1) & 3))) << 4) + 8 * (p4 & 1));
+
+    // row ids of this split -> LDS once; DMASK marks a masked (padding / out-of-range) row
+    for (int i = tid; i < g.k_chunk; i += 512) {
+        int k = kb + i;
+        bool seg2 = k >= g.k_switch;
+        int kl = seg2 ? k - g.k_switch : k;
+        int lim = seg2 ? g.k_valid2 : g.k_valid1;
+        const int64_t* ip = seg2 ? g.k_rows2 : g.k_rows;
+        bool valid = k < ke && kl < lim;
+        ids[i] = valid ? (int)ip[kl] : DMASK;
+    }
+    __syncthreads();                                    // (also drains the id loads: no ordinary vector load is pending from here on)
+    DSTAMP(1);
+    issueF(0, 0);
+    if (GATED) {
+        if (wave == 0) {
+            const int b0 = kb / gate.ts, nb = (min(ke, gate.total_cols) - kb + gate.ts - 1) / gate.ts;
+            const int rc = nb > 0 ? tasks_wait(gate.ctl, gate.fwd_base + b0, nb, lane, 1u) : TW_OK;
+            if (lane == 0) *sh_rc = rc;
+        }
+        __syncthreads();                                // (emits vmcnt(0): the feature pieces above have landed -- harmless, they are needed next)
+        const int rc = *sh_rc;
+        __syncthreads();                                // (the word is rewritten by the next wait)
+        if (rc != TW_OK) return rc;
+        if (gate.timeline && tid == 0) gate.timeline[(size_t)(gate.self_base + vbid) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    issueA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    DSTAMP(2);
+    for (int c = 0; c < nchunks; ++c) {
+        const int st = c & 1;
+        // the other stage was last read in iteration c-1, which every wave has left (the barrier below)
+        if (c + 1 < nchunks) { issueA(c + 1, st ^ 1); issueF(c + 1, st ^ 1); }
+        // fragment reads run four k-steps ahead of their MFMAs (inline asm: behind the ds_read_tr16 builtin hipcc drains the
+        // LDS-DMA queue with s_waitcnt vmcnt(0) in front of every chunk's first read, and its own waits do not count asm loads
+        // anyway); every k-step waits for ITS four reads with a counted lgkmcnt (LDS operations complete in order; at most 16
+        // are outstanding) that names their destinations (guide 5.7, form (ii))
+        const unsigned so = (unsigned)(st * DSTAGE_BYTES);
+        u32x4 fa[4][2];
+        s16x4 flo[4], fhi[4];
+#define DW_READ(ks_, slot_)                                                                                               \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[slot_][0]) : "v"(a_ad[ks_] + so));                                   \
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fa[slot_][1]) : "v"(a_ad[ks_] + so));                       \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(flo[slot_]) : "v"(lds_lo + so), "i"((ks_) * 16 * 256)); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fhi[slot_]) : "v"(lds_hi + so), "i"((ks_) * 16 * 256));
+        DW_READ(0, 0) DW_READ(1, 1) DW_READ(2, 2) DW_READ(3, 3)
+#pragma unroll
+        for (int ks = 0; ks < DKB / 16; ++ks) {
+            const int sl = ks & 3;
+            if (ks <= 4) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(fa[sl][0]), "+v"(fa[sl][1]), "+v"(flo[sl]), "+v"(fhi[sl]) :: "memory");
+            if (ks == 5) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[sl][0]), "+v"(fa[sl][1]), "+v"(flo[sl]), "+v"(fhi[sl]) :: "memory");
+            if (ks == 6) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[sl][0]), "+v"(fa[sl][1]), "+v"(flo[sl]), "+v"(fhi[sl]) :: "memory");
+            if (ks == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[sl][0]), "+v"(fa[sl][1]), "+v"(flo[sl]), "+v"(fhi[sl]) :: "memory");
+            s16x8 v = {flo[sl][0], flo[sl][1], flo[sl][2], flo[sl][3], fhi[sl][0], fhi[sl][1], fhi[sl][2], fhi[sl][3]};
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, v);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[sl][0]), a1 = __builtin_bit_cast(bf16x8, fa[sl][1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);          // keep this k-step's MFMAs in front of the refill and the next wait (guide rule 18)
+            if (ks == 0) { DW_READ(4, 0) }
+            if (ks == 1) { DW_READ(5, 1) }
+            if (ks == 2) { DW_READ(6, 2) }
+            if (ks == 3) { DW_READ(7, 3) }
+        }
+#undef DW_READ
+        // chunk c+1 must have landed before anybody reads it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c < 3) DSTAMP(3 + c);
+    }
+    DSTAMP(6);
+
+    const int n = n0 + wn * 32 + l31;
+    if (n < g.N) {
+        float* out = g.out + (size_t)z * g.slab_stride;
+        u16* o16 = static_cast<u16*>(g.out16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int m = m0 + wm * 64 + i * 32 + acc_row(e, h);
+                if (m >= g.M) continue;
+                if (OM == 0) store_out_f32(out + (size_t)m * g.ldo + n, acc[i][e], g.plain);
+                else {
+                    const u16 v = f2bf(acc[i][e]);
+                    if (OM == 1) o16[(size_t)m * g.ldo + n] = v;
+                    else o16[((size_t)(n >> 6) * g.ldo + m) * 64 + (n & 63)] = v;
+                }
+            }
+    }
+    DSTAMP(7);
+    if (GATED && gate.timeline && tid == 0) gate.timeline[(size_t)(gate.self_base + vbid) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    return TW_OK;
+#undef DSTAMP
+}
+
+template <int AM, int OM>
+__global__ __launch_bounds__(512) void dw_bf16_dma(DwArgsB g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    DwGate none;
+    none.ctl = StepCtl{nullptr, nullptr, nullptr, 0u}; none.fwd_base = none.self_base = 0; none.ts = 32; none.total_cols = 0; none.timeline = nullptr;
+    (void)dw_bf16_body_dma<AM, OM, false>(g, (int)blockIdx.x, none, smem_dyn, nullptr);
+}
+
 template <int AM, int OM>
 __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
     __shared__ __attribute__((aligned(16))) unsigned char dw_lds[DW_LDS_BYTES];
@@ -1183,6 +1397,14 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
 // is taken by the first workgroup that needs its result (tasks_wait), so no wait depends on dispatch order or residency.
 // Handed-off data (dZ^T, slabs, partials) is stored write-through and read with device-coherent loads.
 // --------------------------------------------------------------------------- //
+// the dW body of the one-launch step: the LDS-DMA tile (round 3); -DUMLH_STEP_DW_OLD builds the register-staged one for A/B runs
+#ifdef UMLH_STEP_DW_OLD
+#define UMLH_STEP_DW_BODY dw_bf16_body
+#define UMLH_STEP_DW_LDS DW_LDS_BYTES
+#else
+#define UMLH_STEP_DW_BODY dw_bf16_body_dma
+#define UMLH_STEP_DW_LDS DW_DMA_LDS_BYTES
+#endif
 struct StepShape { int nfwd, ndw, nupd, nfin;
                    int lazy; };   // test switch (UMLH_STEP_LAZY=1): every 4th workgroup leaves its forward and dW home tasks alone,
                                   // as if it had not been dispatched yet -- whoever needs them takes them (tasks_wait)
@@ -1304,7 +1526,7 @@ __device__ __attribute__((noinline)) void step_cold(const StepArgs* kp, int firs
         const int t = sp == 1 ? s0 : (sp == 2 ? s1 : s2);
         int rc = TW_OK;
         if (t < b_dw) { step_fwd_task<CTW, WC>(p, t, smem); --sp; continue; }
-        else if (t < b_upd) rc = dw_bf16_body<0, 0, true>(p.g, t - b_dw, p.gate, smem, sh_ctl);
+        else if (t < b_upd) rc = UMLH_STEP_DW_BODY<0, 0, true>(p.g, t - b_dw, p.gate, smem, sh_ctl);
         else if (t < b_fin) rc = step_update_task<CTW, WC>(p.hf, p.gate, p.sh, t - b_upd, sh_ctl);
         else rc = step_fin_task<CTW, WC>(p, t, smem, sh_ctl);
         if (rc == TW_OK) { task_publish(ctl, t); --sp; }
@@ -1342,7 +1564,7 @@ __global__ __launch_bounds__(512) void step_bf16(StepArgs p) {
 #pragma unroll 1
     for (int i = b + G; i < p.sh.nfwd && !lazy; i += G) step_cold<CTW, WC>(kp, i, -1, 1, smem_dyn, sh_ctl);
     if (sh_ctl[5]) {
-        const int rc = dw_bf16_body<0, 0, true>(p.g, b, p.gate, smem_dyn, sh_ctl);   // the same dynamic LDS, laid out for dW
+        const int rc = UMLH_STEP_DW_BODY<0, 0, true>(p.g, b, p.gate, smem_dyn, sh_ctl);   // the same dynamic LDS, laid out for dW
         if (rc == TW_OK) task_publish(ctl, b_dw + b);
         else if (rc == TW_ABORT) __syncthreads();            // status is set: this task and what depends on it is skipped
         else step_cold<CTW, WC>(kp, rc, b_dw + b, 0, smem_dyn, sh_ctl);   // a forward tile nobody had taken: run it, then this tile from the start (nothing was stored)
@@ -1457,7 +1679,7 @@ int umlh_bf16_launch_transpose_shadow(const float* src, int R, int Cc, int ldd, 
 #define STEP_CASE(CT, W)                                                                                           \
     if (ctw == CT && wc == W) {                                                                                    \
         size_t sm = fwd_smem_bytes_b(CT, W, 1);                                                                    \
-        if (sm < (size_t)DW_LDS_BYTES) sm = DW_LDS_BYTES;                                                          \
+        if (sm < (size_t)UMLH_STEP_DW_LDS) sm = UMLH_STEP_DW_LDS;                                                  \
         static std::atomic<unsigned long long> attr_done{0};  /* bit d: done on device d (the attribute is per device) */ \
         if (!((attr_done.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ULL)) {                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_bf16<CT, W>),                   \
@@ -1513,6 +1735,19 @@ int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const Dw
     return (int)hipErrorInvalidValue;
 }
 
+#define DW_DMA_CASE(A_, O_)                                                                                        \
+    if (am == A_ && om == O_) {                                                                                    \
+        static std::atomic<unsigned long long> attr_done{0};                                                       \
+        if (!((attr_done.load(std::memory_order_acquire) >> (dev_ & 63)) & 1ULL)) {                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_dma<A_, O_>),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, DW_DMA_LDS_BYTES);      \
+            if (e != hipSuccess) return (int)e;                                                                    \
+            attr_done.fetch_or(1ULL << (dev_ & 63), std::memory_order_release);                                    \
+        }                                                                                                          \
+        hipLaunchKernelGGL((dw_bf16_dma<A_, O_>), grid, dim3(512), DW_DMA_LDS_BYTES, stream, c);                   \
+        return (int)hipGetLastError();                                                                             \
+    }
+
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream) {
     if (g->M <= 0 || g->N <= 0) return 0;
     if (g->k_chunk > DIDS || g->k_chunk % (DKT * DNS) != 0 || g->nsplit != splits) return (int)hipErrorInvalidValue;
@@ -1521,6 +1756,14 @@ int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_
     dim3 grid(((g->N + DBN - 1) / DBN) * ((g->M + DBM - 1) / DBM) * splits);
     DwArgsB c = *g;
     c.plain = umlh_plain_stores();
+    // UMLH_BF16_DW=0: the register-staged tile of rounds 1-2 (A/B timing); default: the LDS-DMA tile
+    static const bool old_tile = [] { const char* e = getenv("UMLH_BF16_DW"); return e && atoi(e) == 0; }();
+    if (!old_tile) {
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        DW_DMA_CASE(0, 0) DW_DMA_CASE(1, 1) DW_DMA_CASE(0, 2)
+        return (int)hipErrorInvalidValue;
+    }
     if (am == 0 && om == 0) hipLaunchKernelGGL((dw_bf16<0, 0>), grid, dim3(512), 0, stream, c);
     else if (am == 1 && om == 1) hipLaunchKernelGGL((dw_bf16<1, 1>), grid, dim3(512), 0, stream, c);
     else if (am == 0 && om == 2) hipLaunchKernelGGL((dw_bf16<0, 2>), grid, dim3(512), 0, stream, c);
