@@ -248,8 +248,9 @@ def test_encoder_plan_pool_leases_and_eviction():
 
 
 def test_lr_table_equals_stepwise_schedule():
-    """StepLR.lr_table (vector expression) == lr_at step by step (within one ulp of double) for every schedule / warm-up pair,
-    across the warm-up boundary and past max_iter."""
+    """StepLR.lr_table == lr_at step by step, BIT for bit (blockwise runs use lr_table, stepwise runs lr_at, and the two
+    are claimed bit-identical), for every schedule / warm-up pair, across the warm-up boundary, past max_iter and over the whole
+    12 800-step schedule of HYPER_DICT."""
     import numpy as np
     from engine.optimizer.scheduler import StepLR
 
@@ -264,4 +265,22 @@ def test_lr_table_equals_stepwise_schedule():
                 tab = np.asarray(s.lr_table(n, start=start))
                 ref = np.asarray([s.lr_at(start + i, 1e-3) for i in range(n)])
                 assert tab.shape == ref.shape
-                np.testing.assert_allclose(tab, ref, rtol=4e-16, atol=1e-22)
+                assert tab.tobytes() == ref.tobytes()
+        s = StepLR(Opt(), kind, 12800, warmup_iter=50, warmup_type="linear", warmup_lr=1e-5)
+        tab = np.asarray(s.lr_table(12800, start=0))
+        assert tab.tobytes() == np.asarray([s.lr_at(i, 1e-3) for i in range(12800)]).tobytes()
+
+
+def test_head_optimizer_step_refuses_packed_bias_views_with_a_clear_error():
+    """with bias=True the layer's weight / bias are strided views of one packed tensor; the unfused
+    HeadOptimizer.step() cannot update them (detached moments, non-contiguous operands) and says so instead of failing deep in the
+    multi-tensor launch."""
+    import torch
+    import umlh
+    from engine.optimizer.optim import build_optimizer
+    packed = torch.zeros(6, 8)
+    w = torch.nn.Parameter(packed[:, :5])          # a strided view, as head.py's _pack_linear makes them
+    w.grad = torch.ones_like(w)
+    opt = build_optimizer([w], "adamw", 1e-3, 0.01)
+    with pytest.raises(umlh.UmlhError, match="packed"):
+        opt.step()

@@ -1006,10 +1006,11 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             const bool with_head = fused && h->pending_head && h->fuse >= 2;
             if (fused && umlh_bf16_step_tasks(nb0 + nb1, g.M, g.N, splits, L.n_head, with_head) <= L.ctl_tasks) {
                 // forward + dW (+ update + finalize) as ONE launch of persistent workgroups over claimed tasks (StepCtl)
-                if (++h->fuse_epoch == 0) {                   // tag wrap (2^32 launches): start the epoch-tagged words over
+                if (h->fuse_epoch > 0xFFFFFF00u) {            // tag wrap (2^32 launches): start the epoch-tagged words over
                     HIPCHK((int)hipMemsetAsync(ws(h, L.fuse_flags), 0, sizeof(float) * (size_t)(3 * L.ctl_tasks), st), "step control words");
-                    h->fuse_epoch = 1;
+                    h->fuse_epoch = 0;
                 }
+                ++h->fuse_epoch;
                 HeadFuse hf;
                 if (with_head) { hf = *h->pending_head; hf.n_slabs = splits; hf.n_slabs_img = sp.n_img; }
                 unsigned long long* done = reinterpret_cast<unsigned long long*>(ws(h, L.fuse_flags));

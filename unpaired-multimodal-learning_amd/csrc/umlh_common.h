@@ -325,9 +325,13 @@ constexpr unsigned long long UMLH_SPIN_TICKS = 5000000ull;     // 50 ms of s_mem
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ unsigned ctl_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Tags are compared as OLDER THAN, never as "different" (a word that is newer than the epoch asked about belongs to a task that
+// is long taken and done: the multi-step experiment of round 3 -- several steps' epochs alive in one launch -- ran update tasks
+// twice under contention with "!=").  The host restarts the tags long before they could wrap.
+__device__ __forceinline__ bool tag_older(unsigned tag, unsigned epoch) { return (int)(tag - epoch) < 0; }
 // one lane takes task t; true = it is ours
 __device__ __forceinline__ bool task_take(const StepCtl& c, int t) {
-    return __hip_atomic_fetch_max(c.claim + t, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != c.epoch;
+    return tag_older(__hip_atomic_fetch_max(c.claim + t, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c.epoch);
 }
 // Called by ONE whole wave: waits until tasks [first, first + count) are done.  Returns TW_OK, TW_ABORT (status set: by this
 // wait's time-out or by anybody else) or the id of a task of the range that nobody had taken and that this wave has now
@@ -340,9 +344,9 @@ __device__ __forceinline__ int tasks_wait(const StepCtl& c, int first, int count
         int untaken = 0x7fffffff;
         for (int i = lane; i < count; i += 64) {
             const unsigned long long v = __hip_atomic_load(c.done + first + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool d = (unsigned)(v >> 32) == c.epoch;
+            const bool d = !tag_older((unsigned)(v >> 32), c.epoch);
             ok = ok && d;
-            if (look && !d && ctl_load_u32(c.claim + first + i) != c.epoch) untaken = min(untaken, first + i);
+            if (look && !d && tag_older(ctl_load_u32(c.claim + first + i), c.epoch)) untaken = min(untaken, first + i);
         }
         if (__all(ok)) return TW_OK;
         if (look) {
@@ -351,7 +355,7 @@ __device__ __forceinline__ int tasks_wait(const StepCtl& c, int first, int count
             if (untaken != 0x7fffffff) {
                 unsigned old = c.epoch;
                 if (lane == 0) old = __hip_atomic_fetch_max(c.claim + untaken, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)__builtin_amdgcn_readfirstlane((int)old) != c.epoch) return untaken;
+                if (tag_older((unsigned)__builtin_amdgcn_readfirstlane((int)old), c.epoch)) return untaken;
             }
             if (ctl_load_u32(c.status) != 0u) return TW_ABORT;
             if (__builtin_amdgcn_s_memrealtime() - t0 > UMLH_SPIN_TICKS) {

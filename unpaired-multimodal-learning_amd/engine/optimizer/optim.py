@@ -69,6 +69,13 @@ class HeadOptimizer:
         live = [p for p in g["params"] if p.grad is not None]
         if not live:
             return
+        packed = [p for p in live if not p.data.is_contiguous()]
+        if packed:
+            # bias=True heads (head.py:65,68): weight and bias are strided VIEWS of one packed [out, in_aug] tensor whose
+            # moments live packed in the fused engine; an elementwise update of the views would use detached moments
+            raise umlh.UmlhError("HeadOptimizer.step(): %d parameter(s) are views of a packed [weight | bias] tensor (bias=True "
+                                 "head); step them through the fused engine (model.fused_engine(optimizer, ...).train_step / "
+                                 "finetune.train), which updates the packed tensor and its packed moments" % len(packed))
         ms, vs = [], []
         for p in live:
             st = self.state_for(p)

@@ -55,22 +55,13 @@ class StepLR:
         return list(self._last_lr)
 
     def lr_table(self, n, start=None):
-        """lr_at(k0 .. k0+n-1) as a list.  The post-warm-up part is evaluated as one vector (same expression, double
-        precision; a sweep asks for ~10^5 values): a value may differ from ``lr_at`` in its last bit where numpy's cos and
-        math.cos round differently, far below the float32 the kernels take it in."""
+        """lr_at(k0 .. k0+n-1) as a list of Python floats (doubles: ``Hyper.lr`` / ``GroupItem.lr`` take doubles).  Every entry
+        is formed by the SAME expression as ``lr_at`` -- the cosine tail with ``math.cos`` per element, not a vectorised
+        ``numpy.cos``, whose last bit can differ -- so a blockwise run (lr_table) and a stepwise run (lr_at) see bit-identical
+        learning rates (tests/test_host_api_cpu.py pins it over a 12 800-step schedule)."""
         k0 = self.last_epoch if start is None else start
         base = self.base_lrs[0]
-        head = [self.lr_at(k, base) for k in range(k0, min(k0 + n, self.warmup_iter))]
-        m = n - len(head)
-        if m <= 0:
-            return head
-        import numpy as np
-        t = np.arange(k0 + len(head) - self.warmup_iter, k0 + n - self.warmup_iter, dtype=np.float64)
-        if self.kind == "cosine":
-            tail = base * (1.0 + np.cos(np.pi * t / self.max_iter)) / 2.0
-        else:
-            tail = base * (1.0 - t / self.max_iter)
-        return head + tail.tolist()
+        return [self.lr_at(k, base) for k in range(k0, k0 + n)]
 
 
 def build_lr_scheduler(optimizer, lr_scheduler, warmup_iter, max_iter, warmup_type=None, warmup_lr=None,
