@@ -188,7 +188,12 @@ def main():
             # every rank must take the same loop: a rank whose communicator could not be created (library missing, init
             # error) sends the whole job to the per-step torch.distributed path instead of leaving the others in a collective
             try:
-                ok = 1 if stepper.attach_rccl() else 0
+                # UMLH_DP_P2P=1: the direct peer-to-peer all-reduce (csrc/umlh_p2p.hip) instead of RCCL -- opt-in, the default
+                # transport of the scaling run stays RCCL until the peer-to-peer path has been measured on a multi-GPU node
+                if os.environ.get("UMLH_DP_P2P", "0") == "1":
+                    ok = 1 if stepper.attach_p2p() else 0
+                else:
+                    ok = 1 if stepper.attach_rccl() else 0
             except umlh.UmlhError as exc:
                 print(f"[rank {rank}] C-level RCCL loop unavailable ({exc}); falling back to per-step torch.distributed", file=sys.stderr)
                 ok = 0

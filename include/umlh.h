@@ -237,6 +237,21 @@ int  umlh_micro_launches(umlh_handle_t h, int64_t* out);
  * first task of the range waited on, launch tag, phase}.  It synchronises with the device.  The host mirror raises UmlhError
  * whenever it reads the step scalars and finds the code set.  umlh_step_launches: one-launch steps taken by this handle. */
 int  umlh_step_status(umlh_handle_t h, int32_t* status_out);
+
+/* Direct peer-to-peer all-reduce of the gradient message (csrc/umlh_p2p.hip): reduce-scatter + all-gather over exchange regions
+ * that every rank allocates in its own HBM (umlh_p2p_alloc of umlh_p2p_region_bytes(n_floats of umlh_grad_buffer, n_ranks)),
+ * exports (umlh_p2p_export: a 64-byte hipIpcMemHandle_t to hand to the peers over the caller's store) and maps from its peers
+ * (umlh_p2p_open).  umlh_p2p_attach makes it the handle's transport in place of RCCL / the callback (linear heads; the sums are
+ * formed in rank order, bit-identical on every rank).  No reference call site exists (the reference is single-GPU); SURVEY 8(e)
+ * asks for it because a ring is per-link bound on the xGMI mesh.  Its waits give up after 30 s (a peer that never arrives) and
+ * report through umlh_step_status (code 2).  UNMEASURED on a multi-GPU node: RCCL remains the default transport. */
+uint64_t umlh_p2p_region_bytes(int64_t n_max_floats, int32_t n_ranks);
+int  umlh_p2p_alloc(uint64_t bytes, void** out);
+int  umlh_p2p_free(void* p);
+int  umlh_p2p_export(void* p, void* handle64);
+int  umlh_p2p_open(const void* handle64, void** out);
+int  umlh_p2p_close(void* p);
+int  umlh_p2p_attach(umlh_handle_t h, void* const* regions, int32_t n_ranks, int32_t rank);
 int  umlh_step_launches(umlh_handle_t h, int64_t* out);
 
 /* Data-parallel split of the step: gradients only, laid out as ONE flat fp32

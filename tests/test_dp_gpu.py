@@ -184,7 +184,7 @@ def test_unequal_shards_rank_without_image_rows_applies_the_same_update():
     assert float(g2.abs().max()) == 0.0
 
 
-def _worker_c_loop(rank, world, port, q, precision, proj):
+def _worker_c_loop(rank, world, port, q, precision, proj, transport="gloo"):
     """C-level data-parallel loop: umlh_train_steps with a transport attached runs grad -> all-reduce -> update per step
     from C; the transport here is gloo through the all-reduce callback (RCCL refuses two ranks on one GPU)."""
     sys.path.insert(0, ROOT)
@@ -215,11 +215,14 @@ def _worker_c_loop(rank, world, port, q, precision, proj):
         # global batch k = rows k*B .. k*B + B of a fixed order; rank r takes every world-th row of it
         bi = [torch.arange(k * B + rank, (k + 1) * B, world, device=dev) for k in range(steps)]
         bt = [torch.arange(k * B + rank, (k + 1) * B, world, device=dev) for k in range(steps)]
-        if world > 1:
+        if world > 1 and transport == "p2p":
+            e.init_p2p()                              # direct peer-to-peer all-reduce over IPC-mapped regions (csrc/umlh_p2p.hip)
+        elif world > 1:
             e.set_allreduce(lambda t: dist.all_reduce(t), world)
         sc = torch.zeros(steps, umlh.N_SCALARS, device=dev)
         e.train_steps(ti, bi, tt, bt, [0.05] * steps, first_step=1, alpha=0.5, scalars_out=sc)
         torch.cuda.synchronize()
+        assert e.step_status()[0] == 0
         q.put((rank, e.w_head.cpu().numpy(), e.w_proj.cpu().numpy() if proj else None, sc.cpu().numpy()))
     finally:
         if world > 1:
@@ -293,3 +296,29 @@ def test_rccl_communicator_single_rank_round_trip(monkeypatch):
     diff = np.abs(out[1][0] - out[0][0])
     assert (diff > 2e-6).mean() < 1e-3 and diff.max() < 5e-3          # Adam sign flips at |g| ~ eps aside
     np.testing.assert_allclose(out[1][1][:, :4], out[0][1][:, :4], atol=1e-5)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_p2p_allreduce_two_ranks_equals_gloo_transport_bit_for_bit(precision):
+    """The direct peer-to-peer all-reduce (reduce-scatter + all-gather over hipIpc-mapped exchange regions, csrc/umlh_p2p.hip)
+    drives the C-level data-parallel loop with two ranks (two processes on ONE GPU: the protocol, the IPC plumbing and the
+    epoch-tagged flags are exercised; xGMI is not): after four steps both ranks hold the weights and scalars of the gloo-callback
+    transport BIT for bit (two terms added in rank order = a + b), equal on both ranks, and the status word is clean."""
+    import torch.multiprocessing as mp
+    res = {}
+    for transport in ("gloo", "p2p"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker_c_loop, args=(r, 2, port, q, precision, False, transport)) for r in range(2)]
+        for p in procs:
+            p.start()
+        out = [q.get(timeout=300) for _ in range(2)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        res[transport] = sorted(out, key=lambda t: t[0])
+    for r in range(2):
+        np.testing.assert_array_equal(res["p2p"][r][1], res["gloo"][r][1])
+        np.testing.assert_array_equal(res["p2p"][r][3], res["gloo"][r][3])
+    np.testing.assert_array_equal(res["p2p"][0][1], res["p2p"][1][1])

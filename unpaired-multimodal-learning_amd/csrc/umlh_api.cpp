@@ -46,6 +46,8 @@ int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const Dw
                           unsigned long long* done, unsigned* status, unsigned epoch, int ts, int total_cols, const HeadFuse* hf,
                           unsigned long long* timeline, int cus, int lazy, hipStream_t stream);
 int umlh_bf16_launch_dw(const DwArgsB* g, int splits, int am, int om, hipStream_t stream);
+int umlh_p2p_launch(void* const* regions, int n_ranks, int rank, float* msg, long long n, long long n_max, unsigned epoch, hipStream_t st);
+int umlh_p2p_status_offset(long long n_max, int n_ranks, unsigned long long* off);
 int umlh_enc_launch_bias_act(float* y, const float* b, long long M, int N, int relu, hipStream_t st);
 int umlh_enc_launch_relu_bwd(const float* y, float* dy, long long n, hipStream_t st);
 int umlh_enc_launch_dropout(float* x, long long n, float p, unsigned long long seed, hipStream_t st);
@@ -248,6 +250,9 @@ struct umlh_handle_s {
     int dp_force;               // UMLH_FORCE_DP=1 / umlh_set_allreduce with one rank: take the split path also alone (pricing, tests)
     umlh_allreduce_fn ar_fn;    // custom transport (tests: gloo through a host callback), else RCCL through `comm`
     void* ar_ctx;
+    void* p2p_region[8];        // umlh_p2p_attach: every rank's exchange region as mapped here (p2p_region[rank] = this rank's own)
+    int p2p_on, p2p_rank;       // direct peer-to-peer all-reduce instead of RCCL / the callback
+    unsigned p2p_epoch;
     void* comm;                 // ncclComm_t
     bool comm_owned;
     hipStream_t comm_stream;    // second stream: the head-gradient all-reduce of a 2-layer head runs beside the img_proj backward GEMMs
@@ -346,6 +351,7 @@ int umlh_create(const umlh_config_t* cfg, umlh_handle_t* out) {
     h->frozen_proj_row = -1;
     h->dp_diag = false; h->n_ranks = 1; h->ar_fn = nullptr; h->ar_ctx = nullptr; h->comm = nullptr; h->comm_owned = false;
     h->comm_stream = nullptr; h->overlap_pending = false;
+    h->p2p_on = 0; h->p2p_rank = 0; h->p2p_epoch = 0; memset(h->p2p_region, 0, sizeof(h->p2p_region));
     { const char* e = getenv("UMLH_FORCE_DP"); h->dp_force = (e && atoi(e) == 1) ? 1 : 0; }
     h->stage = nullptr; h->stage_bytes = 0; h->stage_next = 0;
     { const char* e = getenv("UMLH_MICRO"); h->micro_off = (e && atoi(e) == 0) ? 1 : 0; }
@@ -1427,10 +1433,20 @@ int umlh_micro_status(umlh_handle_t h, int32_t* status_out) {
 int umlh_step_status(umlh_handle_t h, int32_t* status_out) {
     if (!h || !h->bound || !status_out) return fail(UMLH_E_INVALID, "umlh_step_status: bad arguments");
     status_out[0] = status_out[1] = status_out[2] = status_out[3] = 0;
-    if (!h->L.fuse_flags) return UMLH_OK;
     DeviceGuard dg_(h->device);
-    const unsigned* st = reinterpret_cast<const unsigned*>(reinterpret_cast<unsigned long long*>(ws(h, h->L.fuse_flags)) + h->L.ctl_tasks) + h->L.ctl_tasks;
-    HIPCHK((int)hipMemcpy(status_out, st, 4 * sizeof(int32_t), hipMemcpyDeviceToHost), "umlh_step_status");
+    if (h->L.fuse_flags) {
+        const unsigned* st = reinterpret_cast<const unsigned*>(reinterpret_cast<unsigned long long*>(ws(h, h->L.fuse_flags)) + h->L.ctl_tasks) + h->L.ctl_tasks;
+        HIPCHK((int)hipMemcpy(status_out, st, 4 * sizeof(int32_t), hipMemcpyDeviceToHost), "umlh_step_status");
+    }
+    if (status_out[0] == 0 && h->p2p_on) {       // the direct all-reduce's waits (30 s bound: a peer that never arrives)
+        unsigned long long off = 0;
+        const long long n_max = 2 * h->L.n_head + h->L.n_proj + 2 + UMLH_N_SCALARS;
+        if (umlh_p2p_status_offset(n_max, h->n_ranks, &off) == 0) {
+            unsigned v = 0;
+            HIPCHK((int)hipMemcpy(&v, static_cast<unsigned char*>(h->p2p_region[h->p2p_rank]) + off, sizeof(v), hipMemcpyDeviceToHost), "umlh_step_status");
+            if (v) { status_out[0] = 2; status_out[1] = (int32_t)(v >> 8); status_out[2] = (int32_t)h->p2p_epoch; status_out[3] = (int32_t)(v & 255u); }
+        }
+    }
     return UMLH_OK;
 }
 
@@ -1503,7 +1519,7 @@ int umlh_train_steps(umlh_handle_t h, const umlh_stream_t* img, const umlh_strea
         return fail(UMLH_E_INVALID, "umlh_train_steps: index/offsets required");
     DeviceGuard dg_(h->device);
     const bool dp = h->n_ranks > 1 || h->dp_force;
-    if (dp && h->n_ranks > 1 && !h->comm && !h->ar_fn)
+    if (dp && h->n_ranks > 1 && !h->comm && !h->ar_fn && !h->p2p_on)
         return fail(UMLH_E_UNBOUND, "umlh_train_steps: %d ranks but no communicator", h->n_ranks);
     if (!dp && micro_eligible(h, img, txt, n_steps)) {       // batch <= 64 linear head: one persistent launch for all n_steps
         MicroItem it{h, img, txt, lr, first_step, alpha, img_alpha, scalars_out};
@@ -1596,6 +1612,7 @@ static int dp_streams(umlh_handle_t h) {
 }
 
 static void dp_release(umlh_handle_t h) {
+    h->p2p_on = 0;
     if (h->comm && h->comm_owned) { RcclApi* r = rccl_api(); if (r) (void)r->comm_destroy(static_cast<ncclComm_t>(h->comm)); }
     h->comm = nullptr; h->comm_owned = false; h->ar_fn = nullptr; h->ar_ctx = nullptr; h->n_ranks = 1;
 }
@@ -1624,6 +1641,21 @@ int umlh_set_comm(umlh_handle_t h, void* nccl_comm, int32_t n_ranks) {
     return nccl_comm ? dp_streams(h) : UMLH_OK;
 }
 
+// regions[q]: rank q's exchange region (umlh_p2p_region_bytes(umlh_grad_buffer floats, n_ranks) bytes from umlh_p2p_alloc on rank
+// q, zero-filled) as mapped into THIS process: regions[rank] the local allocation, the others through umlh_p2p_open of the
+// handles their owners exported.  The caller keeps the mappings alive until the handle is destroyed or another transport is set.
+int umlh_p2p_attach(umlh_handle_t h, void* const* regions, int32_t n_ranks, int32_t rank) {
+    if (!h || !regions || n_ranks < 1 || n_ranks > 8 || rank < 0 || rank >= n_ranks) return fail(UMLH_E_INVALID, "umlh_p2p_attach: bad arguments");
+    if (h->cfg.has_proj) return fail(UMLH_E_INVALID, "umlh_p2p_attach: the 2-layer head overlaps two all-reduces per step on two streams; use RCCL there");
+    for (int q = 0; q < n_ranks; ++q) if (!regions[q]) return fail(UMLH_E_INVALID, "umlh_p2p_attach: region %d is null", q);
+    DeviceGuard dg_(h->device);
+    dp_release(h);
+    for (int q = 0; q < n_ranks; ++q) h->p2p_region[q] = regions[q];
+    h->p2p_on = 1; h->p2p_rank = rank; h->p2p_epoch = 0; h->n_ranks = n_ranks;
+    if (n_ranks == 1) h->dp_force = 1;
+    return dp_streams(h);
+}
+
 int umlh_set_allreduce(umlh_handle_t h, umlh_allreduce_fn fn, void* ctx, int32_t n_ranks) {
     if (!h || n_ranks < 1 || (!fn && n_ranks > 1)) return fail(UMLH_E_INVALID, "umlh_set_allreduce: bad arguments");
     DeviceGuard dg_(h->device);
@@ -1636,6 +1668,12 @@ int umlh_set_allreduce(umlh_handle_t h, umlh_allreduce_fn fn, void* ctx, int32_t
 // SUM all-reduce of `n` floats in place, enqueued on `st`
 static int dp_allreduce(umlh_handle_t h, float* buf, long long n, hipStream_t st) {
     if (n <= 0) return UMLH_OK;
+    if (h->p2p_on) {                 // direct reduce-scatter + all-gather over the peers' mapped regions (umlh_p2p.hip)
+        if (++h->p2p_epoch == 0) h->p2p_epoch = 1;
+        const long long n_max = 2 * h->L.n_head + h->L.n_proj + 2 + UMLH_N_SCALARS;
+        HIPCHK(umlh_p2p_launch(h->p2p_region, h->n_ranks, h->p2p_rank, buf, n, n_max, h->p2p_epoch, st), "p2p all-reduce");
+        return UMLH_OK;
+    }
     if (h->ar_fn) {
         int rc = h->ar_fn(h->ar_ctx, buf, (uint64_t)n, st);
         return rc ? fail(UMLH_E_HIP, "data parallel: the all-reduce callback failed with code %d", rc) : UMLH_OK;

@@ -20,12 +20,12 @@ PREC_IDS = {"fp32": 0, "bf16": 1}
 N_CORE_SCALARS = 8
 N_SCALARS = 12
 
-SOURCES = ["umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_micro.hip", "umlh_kernels_seq.hip", "umlh_kernels_enc.hip", "umlh_api.cpp", "umlh_encoder.cpp"]
+SOURCES = ["umlh_p2p.hip", "umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_micro.hip", "umlh_kernels_seq.hip", "umlh_kernels_enc.hip", "umlh_api.cpp", "umlh_encoder.cpp"]
 EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_freeze_proj_row", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_eval_rows", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
-           "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_step_status", "umlh_step_launches", "umlh_comm_unique_id", "umlh_comm_init_rank",
+           "umlh_train_steps", "umlh_train_steps_grouped", "umlh_micro_status", "umlh_micro_launches", "umlh_step_status", "umlh_step_launches", "umlh_p2p_region_bytes", "umlh_p2p_alloc", "umlh_p2p_free", "umlh_p2p_export", "umlh_p2p_open", "umlh_p2p_close", "umlh_p2p_attach", "umlh_comm_unique_id", "umlh_comm_init_rank",
            "umlh_set_comm", "umlh_set_allreduce", "umlh_seq_mse_forward", "umlh_seq_mse_backward", "umlh_seq_mse_backward_scratch_floats", "umlh_infonce_forward", "umlh_infonce_backward",
            "umlh_random_permutation", "umlh_debug_buffer",
            "umlh_gemm_f32", "umlh_add_inplace", "umlh_bias_act", "umlh_relu_backward", "umlh_dropout", "umlh_colsum",
@@ -186,6 +186,14 @@ def load_library():
     lib.umlh_micro_launches.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.umlh_step_status.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.umlh_step_launches.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.umlh_p2p_region_bytes.restype = u64
+    lib.umlh_p2p_region_bytes.argtypes = [i64, i32]
+    lib.umlh_p2p_alloc.argtypes = [u64, C.POINTER(vp)]
+    lib.umlh_p2p_free.argtypes = [vp]
+    lib.umlh_p2p_export.argtypes = [vp, vp]
+    lib.umlh_p2p_open.argtypes = [vp, C.POINTER(vp)]
+    lib.umlh_p2p_close.argtypes = [vp]
+    lib.umlh_p2p_attach.argtypes = [vp, C.POINTER(vp), i32, i32]
     lib.umlh_comm_unique_id.argtypes = [vp]
     lib.umlh_comm_init_rank.argtypes = [vp, vp, i32, i32]
     lib.umlh_set_comm.argtypes = [vp, vp, i32]

@@ -40,6 +40,15 @@ class DataParallelStepper:
             return False
         return bool(self.engine.init_rccl(self.group))
 
+    def attach_p2p(self) -> bool:
+        """Hand the engine the direct peer-to-peer all-reduce (``HeadEngine.init_p2p``: reduce-scatter + all-gather over
+        hipIpc-mapped exchange regions) instead of RCCL; ``umlh_train_steps`` then runs the data-parallel steps from C as with
+        ``attach_rccl``.  Linear heads only; opt-in (unmeasured on a multi-GPU node)."""
+        if self.world <= 1 or not hasattr(self.engine, "init_p2p") or self.engine.has_proj:
+            return False
+        self.engine.init_p2p(self.group)
+        return True
+
     def invalidate(self) -> None:
         """Call after writing the parameters from outside (load_state_dict, re-init)."""
         self._own_weights = False

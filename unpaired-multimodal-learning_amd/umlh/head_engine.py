@@ -423,6 +423,46 @@ class HeadEngine:
         check(self.lib.umlh_comm_init_rank(self.handle, idb, world, rank), "umlh_comm_init_rank")
         return True
 
+    def init_p2p(self, group=None) -> None:
+        """Attach the direct peer-to-peer all-reduce (csrc/umlh_p2p.hip) over the ranks of ``group``: every rank allocates its
+        exchange region, ``torch.distributed`` (any backend) carries the 64-byte IPC handles, every rank maps its peers' regions
+        and hands the table to ``umlh_p2p_attach``.  Linear heads only.  Unmeasured on a multi-GPU node (RCCL is the default)."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        n_floats = C.c_uint64(0)
+        p = C.c_void_p()
+        check(self.lib.umlh_grad_buffer(self.handle, C.byref(p), C.byref(n_floats)), "umlh_grad_buffer")
+        n_max = 2 * self.num_classes * self.d_shared + (self.d_shared * self.d_img if self.has_proj else 0) + 2 + _lib.N_SCALARS
+        nbytes = int(self.lib.umlh_p2p_region_bytes(n_max, world))
+        if nbytes == 0:
+            raise UmlhError("init_p2p: unsupported world size")
+        own = C.c_void_p()
+        rc = self.lib.umlh_p2p_alloc(nbytes, C.byref(own))
+        if rc:
+            raise UmlhError(f"umlh_p2p_alloc failed (hip error {rc})")
+        hb = (C.c_ubyte * 64)()
+        rc = self.lib.umlh_p2p_export(own, hb)
+        if rc:
+            raise UmlhError(f"umlh_p2p_export failed (hip error {rc})")
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(hb), group=group)
+        regions = (C.c_void_p * world)()
+        opened = []
+        for q in range(world):
+            if q == rank:
+                regions[q] = own
+            else:
+                peer = C.c_void_p()
+                hq = (C.c_ubyte * 64)(*handles[q])
+                rc = self.lib.umlh_p2p_open(hq, C.byref(peer))
+                if rc:
+                    raise UmlhError(f"umlh_p2p_open of rank {q}'s region failed (hip error {rc})")
+                regions[q] = peer
+                opened.append(peer)
+        dist.barrier(group=group)                     # every rank has mapped every region before anybody's first step writes into one
+        check(self.lib.umlh_p2p_attach(self.handle, regions, world, rank), "umlh_p2p_attach")
+        self._p2p = (own, opened, regions)            # kept alive with the engine
+
     def detach_comm(self) -> None:
         """Drop the communicator (``umlh_set_comm(h, NULL, 1)``): ``train_steps`` is single-GPU again and the data-parallel
         step goes through ``grad_step`` / ``apply_update`` with the caller's all-reduce."""
