@@ -184,7 +184,8 @@ def main():
                                                                  file=sys.stderr, flush=True), os._exit(4)))
             watchdog.daemon = True
             watchdog.start()
-        if world > 1 and not rehearsal and not args.dp_host_loop:
+        p2p_req = os.environ.get("UMLH_DP_P2P", "0") == "1"
+        if world > 1 and (not rehearsal or p2p_req) and not args.dp_host_loop:     # (the peer-to-peer transport also works with ranks sharing a GPU)
             # every rank must take the same loop: a rank whose communicator could not be created (library missing, init
             # error) sends the whole job to the per-step torch.distributed path instead of leaving the others in a collective
             try:
@@ -197,7 +198,7 @@ def main():
             except umlh.UmlhError as exc:
                 print(f"[rank {rank}] C-level RCCL loop unavailable ({exc}); falling back to per-step torch.distributed", file=sys.stderr)
                 ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if not rehearsal else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             c_level_dp = bool(int(flag.item()))
             if ok and not c_level_dp:
@@ -393,7 +394,7 @@ def main():
                                       "lr 1e-3 wd 0.01, warm-up 50 + cosine 12800",
                           "n_img_rows": N_IMG, "n_txt_rows": N_TXT, "global_batch": 2 * BATCH * world,
                           "parallelism": f"dp{world}" + (" (REHEARSAL: ranks share GPUs, gloo all-reduce -- not a measurement)" if rehearsal else ""),
-                          "dp_stepping": ("c-level rccl" if head["c_level_dp"] else "python per step") if dp_path else "single gpu",
+                          "dp_stepping": (("c-level peer-to-peer (umlh_p2p)" if os.environ.get("UMLH_DP_P2P", "0") == "1" else "c-level rccl") if head["c_level_dp"] else "python per step") if dp_path else "single gpu",
                           "precision_mode": args.precision, "order_rng": args.order_rng, "steps_per_call": args.block,
                           "timing": f"median of {repeats} blocks of {args.steps} steps after {args.prime}+{args.warmup} untimed steps; "
                                     "each block draws and marshals the next block's index vectors after enqueuing its own steps"},
