@@ -141,8 +141,13 @@ __global__ __launch_bounds__(256) void transpose_shadow_kernel(const float* __re
 // Streamed operand W: global -> registers (fragment-major shadow, PD k-steps deep ring per wave,
 // 16 KiB in flight per wave).  Shared operand X: the block's TS sample rows stay resident in LDS
 // for a K-block of XK and every wave reads its B fragment with one ds_read_b128 per k-step.
+// TakeHook (the one-launch step): the workgroup's takes of its home tasks were ISSUED at kernel start (returning atomics of
+// threads 0..3, result in `old`) but not waited for; the forward body starts on its loads right away and settles the takes --
+// verdicts into verdict[0..3] -- in front of its first barrier, where wave 0 waits for its own X loads anyway.  Nothing has
+// been stored by then: a tile that turns out to be somebody else's (this workgroup arrived late and a waiter took it) returns false.
+struct TakeHook { unsigned old; unsigned epoch; int* verdict; };
 template <int CTW, int WC, int STW>
-__device__ __forceinline__ void fwd_ce_bf16_body(const FwdArgsB& a, const int bid, unsigned char* smem_raw) {
+__device__ __forceinline__ bool fwd_ce_bf16_body(const FwdArgsB& a, const int bid, unsigned char* smem_raw, const TakeHook* hook = nullptr) {
     constexpr int WS = 8 / WC;
     constexpr int CPAD = 32 * CTW * WC;
     constexpr int TS = 32 * STW * WS;
@@ -224,7 +229,9 @@ __device__ __forceinline__ void fwd_ce_bf16_body(const FwdArgsB& a, const int bi
             int col = 8 * ((tid + 512 * q) % (XK / 8));
             xr[q] = *reinterpret_cast<const u32x4*>(xsrc[q] + kb0 + min(col, kbw - 8) - col);
         }
+        if (hook != nullptr && kb0 == 0 && tid < 4) hook->verdict[tid] = tag_older(hook->old, hook->epoch) ? 1 : 0;
         __syncthreads();                                         // previous block fully consumed
+        if (hook != nullptr && kb0 == 0 && !hook->verdict[0]) return false;   // (uniform: the forward tile's verdict)
 #pragma unroll
         for (int q = 0; q < NPX; ++q) {
             int p = tid + 512 * q;
@@ -282,7 +289,7 @@ __device__ __forceinline__ void fwd_ce_bf16_body(const FwdArgsB& a, const int bi
 #pragma unroll
                 for (int i = 0; i < 16; ++i) t += acc[ct][st][i];
         if (t == 123.456f) a.partials[0] = t;
-        return;
+        return true;
     }
     // ---------------- epilogue (per 32-sample tile of this wave) ----------------
     // VALU-bound (64 logits per lane per tile), so every pass is kept to very few instructions per
@@ -526,13 +533,14 @@ __device__ __forceinline__ void fwd_ce_bf16_body(const FwdArgsB& a, const int bi
         store_out_f32(o + 0, l, a.plain); store_out_f32(o + 1, c, a.plain); store_out_f32(o + 2, g, a.plain); store_out_f32(o + 3, 0.f, a.plain);
     }
     STAMP(5);
+    return true;
 #undef STAMP
 }
 
 template <int CTW, int WC, int STW>
 __global__ __launch_bounds__(512) void fwd_ce_bf16(FwdArgsB a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    fwd_ce_bf16_body<CTW, WC, STW>(a, (int)blockIdx.x, smem_dyn);
+    (void)fwd_ce_bf16_body<CTW, WC, STW>(a, (int)blockIdx.x, smem_dyn);
 }
 
 // --------------------------------------------------------------------------- //
@@ -1496,10 +1504,10 @@ __device__ __forceinline__ int step_update_task(const HeadFuse& hf, const DwGate
 struct StepArgs { FwdArgsB a; DwArgsB g; DwGate gate; StepShape sh; HeadFuse hf; };   // THE kernel argument (one struct: the cold
                                                                                        // path below re-reads it from the kernarg segment)
 template <int CTW, int WC>
-__device__ __forceinline__ void step_fwd_task(const StepArgs& p, int t, unsigned char* smem) {
+__device__ __forceinline__ void step_fwd_task(const StepArgs& p, int t, unsigned char* smem, const TakeHook* hook = nullptr) {
     unsigned long long* tl = p.gate.timeline ? p.gate.timeline + (size_t)t * 4 : nullptr;
     if (tl && threadIdx.x == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
-    fwd_ce_bf16_body<CTW, WC, 1>(p.a, t, smem);
+    if (!fwd_ce_bf16_body<CTW, WC, 1>(p.a, t, smem, hook)) return;   // (taken by somebody else: nothing was stored)
     if (tl && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[2] = __builtin_amdgcn_s_memrealtime(); }
     task_publish(p.gate.ctl, t);
 }
@@ -1570,6 +1578,7 @@ __global__ __launch_bounds__(512) void step_bf16(StepArgs p) {
     const bool lazy = p.sh.lazy && (b & 3) == 1;
     // all first home tasks are taken NOW, by four lanes of one instruction: the takes of the later phases cost nothing when
     // their turn comes, and nobody who waits for one of them finds it untaken while this workgroup is still in an earlier phase
+    TakeHook hook = {ctl.epoch, ctl.epoch, sh_ctl + 4};       // (old == epoch reads as "not mine")
     if (threadIdx.x < 4) {
         const int k = (int)threadIdx.x;
         int t = -1;
@@ -1577,10 +1586,16 @@ __global__ __launch_bounds__(512) void step_bf16(StepArgs p) {
         if (k == 1 && !lazy && b < p.sh.ndw) t = b_dw + b;
         if (k == 2 && p.sh.nfin > 0 && b == G - 1) t = b_fin;
         if (k == 3 && b < p.sh.nupd) t = b_upd + b;
-        sh_ctl[4 + k] = (t >= 0 && task_take(ctl, t)) ? 1 : 0;
+        if (t >= 0) hook.old = __hip_atomic_fetch_max(ctl.claim + t, ctl.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // issued, not waited for
     }
-    __syncthreads();
-    if (sh_ctl[4]) step_fwd_task<CTW, WC>(p, b, smem_dyn);
+    if (!lazy && b < p.sh.nfwd) {
+        // the forward tile starts on its loads NOW and settles the four takes in front of its first barrier (TakeHook): the
+        // round trip of the atomics (0.5-1 us when 256 workgroups start together) is off the step's critical path
+        step_fwd_task<CTW, WC>(p, b, smem_dyn, &hook);
+    } else {
+        if (threadIdx.x < 4) sh_ctl[4 + threadIdx.x] = tag_older(hook.old, ctl.epoch) ? 1 : 0;
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int i = b + G; i < p.sh.nfwd && !lazy; i += G) step_cold<CTW, WC>(kp, i, -1, 1, smem_dyn, sh_ctl);
     if (sh_ctl[5]) {
