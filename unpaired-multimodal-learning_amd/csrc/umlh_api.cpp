@@ -1098,6 +1098,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
     fa.row_stats = h->row_stats;
     fa.stamps = (h->dbg_fwd == 9 || h->dbg_fwd >= 20) ? reinterpret_cast<unsigned long long*>(ws(h, L.dbg)) : nullptr;
     fa.dbg = h->dbg_fwd;
+    fa.learn = c.learnable_temp;
     if (L.w32s) {
         // refreshed here unless the previous step of the same umlh_train_steps call (or the data-parallel update) just wrote
         // it from its update kernel (between calls the caller may have rewritten w_head)

@@ -65,6 +65,7 @@ struct FwdArgs {
     unsigned long long* stamps;  // diagnostics (UMLH_DBG_FWD=9): [grid][8 waves][8] cycle stamps, else NULL
     const float* Ws;             // fp32 fragment-major shadow of W (w_shadow32_kernel), current; NULL = stage W through LDS
     int   dbg;                   // timing-only ablations of the streamed main loop (analysis build -DUMLH_ABLATIONS only): 21 no W refills, 22 no B reads, 23 both
+    int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale); 0: the per-element fma is skipped
 };
 
 // Elementwise tail of a dense layer of the MultiBench encoder, applied to v = alpha * sum (element (m, n), flat index

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     // e = exp(raw * scale - max), kept in the accumulators for the dZ pass
     float se = 0.f, serw = 0.f;
     const float nmx = -mx;
+    const bool learn = a.learn != 0;
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) {
         const int cbase = wave_c0 + ct * 32;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
                 const float raw = acc[ct][i];
                 const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(raw, scale, nmx) * LOG2E);
                 se += e;
-                serw = __builtin_fmaf(e, raw, serw);
+                if (learn) serw = __builtin_fmaf(e, raw, serw);           // (wave-uniform: only learnable logit scales need it)
                 acc[ct][i] = e;
             }
         }
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     if (a.dzt != nullptr) {       // rows past the segment write zeros: the dW GEMM needs no masking of dZ^T
         const float coef = valid ? sg.w_over_rows * scale : 0.f;
         const float inv = 1.f / se;
+        const float ic = inv * coef;                                  // one multiply per element (p * coef with p = e * inv differs in the last bit only)
         // every wave has passed the last barrier of the main loop (and the exchanges above): the tile buffers are free.
         // Wave-private staging tile [CTW*32 class rows][32 samples] fp32, no padding: the ds_write_b32 of a register is 32
         // consecutive floats per lane half, the ds_read_b128 of 8 rows x 8 quads is conflict-free in the 16-lane groups
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) stg[(ct * 32 + acc_row(i, h)) * 32 + l31] = (acc[ct][i] * inv) * coef;
+            for (int i = 0; i < 16; ++i) stg[(ct * 32 + acc_row(i, h)) * 32 + l31] = acc[ct][i] * ic;
         if (mine) {                                          // the one-hot term, by the lane that owns the label's logit
             const float ey = __builtin_amdgcn_exp2f(__builtin_fmaf(rawy_lane, scale, nmx) * LOG2E);
             stg[rel * 32 + l31] = (ey * inv - 1.f) * coef;
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
 // --------------------------------------------------------------------------- //
 constexpr int DWKC = 32;                                  // reduction rows per staged chunk (one 128-B line of a dZ^T row)
 constexpr int DWLD = DWKC + 4;                            // floats per LDS row (b128 reads of 16 lanes cover all 64 banks)
-constexpr int DWKIDS = 2048;                              // reduction rows per split whose row ids fit the LDS table
+constexpr int DWKIDS = 4096;                              // reduction rows per split whose row ids fit the LDS table (16 KB; round 3: was 2048, which sent cfg3's dW_head -- 2 splits of 4096 rows -- to the 64x64 gemm_f32 tile: 812 us instead of ~300)
 constexpr size_t DW_SMEM = sizeof(float) * 4 * 128 * DWLD + sizeof(int) * DWKIDS;
 __global__ __launch_bounds__(256) void dw_f32(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float dw_smem[];
