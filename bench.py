@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--dp-host-loop", action="store_true", help="N>1: per-step Python stepping (torch.distributed all_reduce) instead of the C-level RCCL loop")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the additional fp32 parity-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg3", action="store_true", help="N=1: also time BASELINE configs[2] (2-layer head 1024 -> 3200, C=1000, 4096+4096 rows) "
+                                                       "in both precision modes and report it under the extra key 'cfg3' (off by default)")
     ap.add_argument("--order-rng", default="device", choices=["device", "torch-cpu"],
                     help="epoch permutations drawn on the GPU (default) or by the reference-identical CPU sampler")
     ap.add_argument("--block", type=int, default=25, help="steps per umlh_train_steps call (host prepares the next block meanwhile)")
@@ -407,9 +409,56 @@ def main():
                                        "dtype": "f32", "roofline": other["roofline"]}
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
+        if args.cfg3 and world == 1:
+            out["cfg3"] = measure_cfg3(torch, umlh, device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_cfg3(torch, umlh, device):
+    """BASELINE configs[2] (DINOv2-L 1024-d image rows -> img_proj 3200 -> head C=1000, OpenLLaMA-width text rows, 4096+4096 rows per
+    step; reference head.py:64-66,79-82): a parity-test case, timed here as an extra key only.  Blocks of consecutive steps through
+    umlh_train_steps, index vectors drawn outside the timed region, median of 5 blocks."""
+    import statistics
+    import time
+    d_img, d_sh, C, B, n_img, n_txt = 1024, 3200, 1000, 4096, 65536, 8192
+    flop = 2.0 * (B * d_img * d_sh * 2 + 2 * B * d_sh * C * 2 + B * C * d_sh)      # H, dW_proj | fwd, dW_head | dH^T
+    g = torch.Generator(device=device).manual_seed(3)
+    xi = torch.nn.functional.normalize(torch.randn(n_img, d_img, generator=g, device=device), dim=1)
+    xt = torch.nn.functional.normalize(torch.randn(n_txt, d_sh, generator=g, device=device), dim=1)
+    yi = torch.randint(0, C, (n_img,), generator=g, device=device)
+    yt = torch.randint(0, C, (n_txt,), generator=g, device=device)
+    res = {"workload": "cfg3: 2-layer head 1024 -> 3200 -> 1000, 4096 img + 4096 txt rows/step, AdamW", "flop_per_step": flop}
+    for precision, steps in (("bf16", 40), ("fp32", 10)):
+        e = umlh.HeadEngine(d_img, d_sh, C, has_proj=True, optimizer="adamw", weight_decay=0.01, max_rows_img=B, max_rows_txt=B,
+                            precision=precision, device=device)
+        e.w_head.normal_(0, 0.02)
+        e.w_proj.normal_(0, 0.02)
+        ti = (xi, yi, umlh.to_bf16(xi)) if precision == "bf16" else (xi, yi)
+        tt = (xt, yt, umlh.to_bf16(xt)) if precision == "bf16" else (xt, yt)
+        times, k0 = [], 1
+        sc = torch.zeros(steps, umlh.N_SCALARS, device=device)
+        for rep in range(6):
+            bi = [torch.randint(0, n_img, (B,), generator=g, device=device) for _ in range(steps)]
+            bt = [torch.randint(0, n_txt, (B,), generator=g, device=device) for _ in range(steps)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e.train_steps(ti, bi, tt, bt, [1e-3] * steps, first_step=k0, scalars_out=sc)
+            torch.cuda.synchronize()
+            if rep:
+                times.append((time.perf_counter() - t0) / steps)
+            k0 += steps
+        e.check_status()
+        dt = statistics.median(times)
+        peak = PEAK[precision] * 1e12
+        res[precision] = {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(2 * B / dt, 1),
+                          "step_frac_of_mfma_roof": round(flop / peak / dt, 4),
+                          "final_loss": [round(float(v), 4) for v in sc[-1][:2].tolist()]}
+        if not all(math.isfinite(v) for v in res[precision]["final_loss"]):
+            raise SystemExit(f"bench cfg3 ({precision}): non-finite loss {res[precision]['final_loss']}")
+        del e
+    return res
 
 
 class FeatureTableAsText:

@@ -142,7 +142,7 @@ typedef struct {
 #define UMLH_N_SCALARS    12
 
 const char* umlh_last_error(void);
-int  umlh_version(void);        /* ABI revision: 3 = round 2 (grouped / micro / data-parallel / encoder-plan / InfoNCE entry points) */
+int  umlh_version(void);        /* ABI revision: 3 = round 2 (grouped / micro / data-parallel / encoder-plan / InfoNCE entry points); 4 = round 3 (umlh_step_status / umlh_step_launches, umlh_p2p_*) */
 
 /* Bytes of workspace a handle with this config needs (0 on invalid config). */
 uint64_t umlh_workspace_bytes(const umlh_config_t* cfg);
@@ -156,6 +156,10 @@ int  umlh_bind(umlh_handle_t h, const umlh_buffers_t* bufs);
 /* Per-step gradient diagnostics on/off (finetune.py:190-191,203-206: the reference computes them on
  * every step with two extra backward passes; here they ride on the slab reduction).  Off by default. */
 int  umlh_enable_diagnostics(umlh_handle_t h, int32_t on);
+/* Heads with bias (head.py:65,68 bias=True, run as packed rows [weight | bias | 0...]): the reference forms its
+ * diagnostics over head.weight only (finetune.py:190-191), so only columns [0, cols) of every class row of w_head enter the
+ * dot product, the norms and the sign-agreement count (cols = 0 or d_shared: all columns). */
+int  umlh_set_diagnostic_columns(umlh_handle_t h, int32_t cols);
 
 /* img_proj WITH bias (head.py:65 `bias=True`, run as a bias-free projection over rows [x | 1 | 0...]): row `row` of w_proj is the
  * constant row that copies the ones column into the projected rows (the head's own bias column needs it); the optimizer

@@ -29,14 +29,15 @@ def run(tag, d_img, d_sh, C, B, proj, precision, n_img=65536, n_txt=8192, steps=
     ti = (xi, yi, umlh.to_bf16(xi)) if precision == "bf16" else (xi, yi)
     tt = (xt, yt, umlh.to_bf16(xt)) if precision == "bf16" else (xt, yt)
 
-    def block(n, k0):
-        bi = [torch.randint(0, n_img, (B,), generator=g, device=DEV) for _ in range(n)]
-        bt = [torch.randint(0, n_txt, (B,), generator=g, device=DEV) for _ in range(n)]
-        e.train_steps(ti, bi, tt, bt, [1e-3] * n, first_step=k0)
-    block(20, 1)
+    def draw(n):                                      # index vectors are drawn outside the timed region
+        return ([torch.randint(0, n_img, (B,), generator=g, device=DEV) for _ in range(n)],
+                [torch.randint(0, n_txt, (B,), generator=g, device=DEV) for _ in range(n)])
+    bi, bt = draw(20)
+    e.train_steps(ti, bi, tt, bt, [1e-3] * 20, first_step=1)
+    bi, bt = draw(steps)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    block(steps, 21)
+    e.train_steps(ti, bi, tt, bt, [1e-3] * steps, first_step=21)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"config": tag, "precision": precision, "d_img": d_img, "d_shared": d_sh, "C": C, "rows_per_step": 2 * B,

@@ -391,6 +391,73 @@ def test_head_with_bias_matches_reference(tag, kind, precision):
     assert any(v.shape == (C,) for v in st.values())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["uml_d96_c37_adamw_learn", "mlp_d48_t64_c10_adamw_learn", "uml_d128_c20_sgd_fixed"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bias_head_with_learnable_temperature_and_diagnostics_matches_reference(tag, precision):
+    """Round 3: bias=True TOGETHER with learnable_temp=True (head.py:65-70) and the per-step gradient diagnostics of a bias head
+    (finetune.py:190-191,203-206: autograd.grad with respect to head.weight ONLY, so the bias column and the padding of the packed
+    [weight | bias | 0...] rows must not enter the dot product, the norms or the sign-agreement rate).  Golden vectors from the
+    reference's own UML class, autograd, build_optimizer and build_lr_scheduler (tests/golden/bias_heads_r3.npz,
+    oracle/make_golden_bias_r3.py): per-step losses, diagnostics, logit scales; final weights and biases."""
+    import umlh
+    from engine.models.head import UML
+    from engine.optimizer.optim import build_optimizer
+    from engine.optimizer.scheduler import build_lr_scheduler
+    g = load_golden("bias_heads_r3")
+    d, C, Bi, Bt, steps, alpha, wd, oid, t_in, learn = g[f"{tag}::cfg"]
+    d, C, steps, t_in, learn = int(d), int(C), int(steps), int(t_in), bool(learn)
+    optim = {2: "adamw", 1: "adam", 0: "sgd"}[int(oid)]
+    m = UML(d, t_in, C, bias=True, learnable_temp=learn).to(DEV)
+    sd = {"head.weight": torch.as_tensor(g[f"{tag}::w0"]), "head.bias": torch.as_tensor(g[f"{tag}::b0"])}
+    if t_in:
+        sd.update({"img_proj.weight": torch.as_tensor(g[f"{tag}::pw0"]), "img_proj.bias": torch.as_tensor(g[f"{tag}::pb0"])})
+    if learn:
+        sd.update({"img_scale": torch.tensor(2.0), "txt_scale": torch.tensor(1.5)})
+    m.load_state_dict(sd)
+    xi, yi, xt, yt = (_t(g[f"{tag}::{k}"], dt) for k, dt in (("xi", torch.float32), ("yi", torch.int64), ("xt", torch.float32), ("yt", torch.int64)))
+    ii, ti = g[f"{tag}::idx_i"], g[f"{tag}::idx_t"]
+    opt = build_optimizer(m.parameters(), optim, 1e-3, float(wd))
+    sch = build_lr_scheduler(opt, "cosine", 2, 100, warmup_type="linear", warmup_lr=1e-5)
+    eng = m.fused_engine(opt, 64, 64, precision=precision)
+    eng.enable_diagnostics(True)
+    sc = torch.zeros(steps, umlh.N_SCALARS, device=DEV)
+    scales = []
+    for k in range(steps):
+        assert abs(opt.param_groups[0]["lr"] - float(g[f"{tag}::lrs"][k])) < 1e-12
+        eng.train_step(umlh.RowBatch(xi, yi, _t(ii[k], torch.int64)), umlh.RowBatch(xt, yt, _t(ti[k], torch.int64)),
+                       lr=opt.param_groups[0]["lr"], step=k + 1, alpha=float(alpha), scalars_out=sc[k])
+        opt.step_count += 1
+        sch.step()
+        scales.append([float(m.img_scale.detach()), float(m.txt_scale.detach())])
+    torch.cuda.synchronize()
+    eng.check_status()
+    rows = sc.cpu()
+    got = rows.numpy()[:, [umlh.S_LOSS_IMG, umlh.S_LOSS_TXT]]
+    f32 = precision == "fp32"
+    np.testing.assert_allclose(got, g[f"{tag}::losses"], atol=1e-4 if f32 else 0.05, rtol=1e-5 if f32 else 5e-3)
+    ref_d = g[f"{tag}::diag"]                                   # [steps][cos, |g_img|, |g_txt|, agreement]
+    for k in range(steps):
+        dg = umlh.grad_diagnostics(rows[k], m.head.weight.numel(), 1, 1)
+        tol = 2e-4 if f32 else 3e-2
+        assert abs(dg["grad_direction_sim"] - ref_d[k, 0]) < tol + (0 if f32 else 0.05 * abs(ref_d[k, 0]))
+        np.testing.assert_allclose([dg["img_grad_norm"], dg["txt_grad_norm"]], ref_d[k, 1:3], rtol=1e-4 if f32 else 3e-2)
+        # sign flips of near-zero entries: a handful of the C * d elements in fp32, a few percent with bf16 operands
+        assert abs(dg["grad_agreement_rate"] - ref_d[k, 3]) < (2e-3 if f32 else 4e-2)
+    if learn:
+        np.testing.assert_allclose(np.asarray(scales), g[f"{tag}::scales"], atol=2e-6 if f32 else 2e-3)
+    lim = 2 * float(np.sum(g[f"{tag}::lrs"])) + 1e-6
+    pairs = [(m.head.weight.detach().cpu().numpy(), g[f"{tag}::w1"]), (m.head.bias.detach().cpu().numpy(), g[f"{tag}::b1"])]
+    if t_in:
+        pairs += [(m.img_proj.weight.detach().cpu().numpy(), g[f"{tag}::pw1"]), (m.img_proj.bias.detach().cpu().numpy(), g[f"{tag}::pb1"])]
+    for got_p, ref in pairs:
+        diff = np.abs(got_p - ref)
+        assert diff.max() <= lim
+        if f32:
+            assert (diff > 2e-6 + 1e-4 * np.abs(ref)).mean() < 5e-3
+    assert float(m._packed[:, (t_in or d) + 1:].abs().max()) == 0.0        # the padding columns never move
+
+
 _F32_FWD_SCRIPT = r"""
 import sys, hashlib, numpy as np, torch
 sys.path.insert(0, sys.argv[1])

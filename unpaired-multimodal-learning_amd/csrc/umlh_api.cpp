@@ -231,6 +231,7 @@ struct umlh_handle_s {
     float* diag_dst;            // where this step's 4 gradient diagnostics go (written by the head-step launch)
     int n_slabs_img;            // dW_head slabs that hold image rows (the rest hold text rows)
     bool diagnostics;           // umlh_enable_diagnostics
+    int  diag_cols = 0;         // umlh_set_diagnostic_columns (0 = every column of w_head)
     float* row_stats;           // per-row {CE, correct} output of the next forward (umlh_eval_rows), else NULL
     int dbg_fwd, dbg_dw;        // timing-only ablation / cycle-stamp switches (UMLH_DBG_FWD / UMLH_DBG_DW), read once at create
     hipEvent_t ev[UMLH_N_PHASES + 1];   // phase boundaries, valid when profiling
@@ -285,13 +286,20 @@ static inline void mark(umlh_handle_t h, int i, hipStream_t st) {
 }
 
 const char* umlh_last_error(void) { return g_err; }
-int umlh_version(void) { return 3; }   // 3: round 2 (grouped / micro / data-parallel / encoder-plan / InfoNCE entry points, umlh_enc_layer_t.seed_device, umlh_seq_mse_backward scratch)
+int umlh_version(void) { return 4; }   // 3: round 2 (grouped / micro / data-parallel / encoder-plan / InfoNCE entry points, umlh_enc_layer_t.seed_device, umlh_seq_mse_backward scratch); 4: round 3 (umlh_step_status / _launches, umlh_p2p_*)
 
 int umlh_freeze_proj_row(umlh_handle_t h, int32_t row) {
     if (!h) return fail(UMLH_E_INVALID, "umlh_freeze_proj_row: null handle");
     if (row >= 0 && (!h->cfg.has_proj || row >= h->cfg.d_shared || h->cfg.d_img % 4 != 0))
         return fail(UMLH_E_INVALID, "umlh_freeze_proj_row: row %d of a [%d, %d] img_proj (needs img_proj and d_img %% 4 == 0)", row, h->cfg.d_shared, h->cfg.d_img);
     h->frozen_proj_row = row < 0 ? -1 : row;
+    return UMLH_OK;
+}
+
+int umlh_set_diagnostic_columns(umlh_handle_t h, int32_t cols) {
+    if (!h) return fail(UMLH_E_INVALID, "umlh_set_diagnostic_columns: null handle");
+    if (cols < 0 || cols > h->cfg.d_shared) return fail(UMLH_E_INVALID, "umlh_set_diagnostic_columns: cols must be in [0, d_shared]");
+    h->diag_cols = cols == h->cfg.d_shared ? 0 : cols;
     return UMLH_OK;
 }
 
@@ -1246,6 +1254,7 @@ static int train_step_impl(umlh_handle_t h, const umlh_batch_t* img, const umlh_
     dg.ticket = reinterpret_cast<unsigned*>(dg.part + 4 * ((h->L.n_head + 1023) / 1024 + 2));
     dg.inv_w0 = hy->img_alpha != 0.f ? 1.f / hy->img_alpha : 0.f;
     dg.inv_w1 = hy->alpha != 0.f ? 1.f / hy->alpha : 0.f;
+    dg.cols = h->diag_cols;
     if (c.d_shared % 8 == 0) {
         // one launch: slab sum + optimizer + (bf16) next step's W shadow + scalars / logit scales
         const bool bf = c.precision == UMLH_PREC_BF16;
@@ -1836,6 +1845,7 @@ static int apply_update_impl(umlh_handle_t h, const umlh_hyper_t* hy, float* sca
         dg.dst = nullptr; dg.n_slabs_img = 1; dg.inv_w0 = dg.inv_w1 = 0.f;
         dg.part = ws(h, h->L.diag_part);
         dg.ticket = reinterpret_cast<unsigned*>(dg.part + 4 * ((h->L.n_head + 1023) / 1024 + 2));
+        dg.cols = h->diag_cols;
         if (h->dp_diag) {
             // the two all-reduced per-modality gradients are the two "slabs" of the update kernel: it sums them, steps the
             // weights and accumulates dot / norms / sign agreement of the GLOBAL gradients (finetune.py:203-206)

@@ -215,7 +215,9 @@ struct DiagArgs {
     float inv_w0, inv_w1;        // 1 / loss weight of each modality (0 if the weight is 0)
     float* part;                 // [blocks][4] per-workgroup partial sums; the workgroup that takes the LAST ticket adds them
     unsigned* ticket;            // in a fixed order (lane l: blocks l, l+64, ...; then a fixed lane tree) -> dst: the values do
-};                               // not depend on the order the workgroups finished in.  ticket is 0 between launches.
+                                 // not depend on the order the workgroups finished in.  ticket is 0 between launches.
+    int   cols = 0;              // > 0: only columns [0, cols) of every class row count (heads with bias: the packed row is
+};                               // [weight | bias | 0...] and the reference's diagnostics are over head.weight only, finetune.py:190-191)
 
 // torch.optim single-tensor update of one element (see oracle/uml_oracle.py
 // optimizer_step for the restated recurrence and its reference citations).

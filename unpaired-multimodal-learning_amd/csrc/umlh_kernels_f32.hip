@@ -1171,15 +1171,18 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
     if (dg.dst != nullptr) {                                 // uniform over the grid
         float dot = 0.f, n2i = 0.f, n2t = 0.f, agree = 0.f;
         if (live) {
+            const int col0 = dg.cols > 0 ? (int)(i % K) : 0;   // (K is a multiple of 4: the four elements share a class row)
+            const int lim = dg.cols > 0 ? dg.cols : 0x7fffffff;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float a = gi[j] * dg.inv_w0;
-                const float b = gt[j] * dg.inv_w1;
+                const bool in = col0 + j < lim;
+                const float a = in ? gi[j] * dg.inv_w0 : 0.f;
+                const float b = in ? gt[j] * dg.inv_w1 : 0.f;
                 dot = __builtin_fmaf(a, b, dot);
                 n2i = __builtin_fmaf(a, a, n2i);
                 n2t = __builtin_fmaf(b, b, n2t);
                 const int sa = (a > 0.f) - (a < 0.f), sb = (b > 0.f) - (b < 0.f);
-                agree += sa == sb ? 1.f : 0.f;
+                agree += in && sa == sb ? 1.f : 0.f;
             }
         }
 #pragma unroll
@@ -1508,7 +1511,7 @@ int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride
     long long n4 = (long long)C * K / 4;
     int blocks = (int)((n4 + 255) / 256) + 1;                 // + the finalize block
     DiagArgs d;
-    if (dg) d = *dg; else { d.dst = nullptr; d.n_slabs_img = n_slabs; d.inv_w0 = d.inv_w1 = 0.f; d.part = nullptr; d.ticket = nullptr; }
+    if (dg) d = *dg; else { d.dst = nullptr; d.n_slabs_img = n_slabs; d.inv_w0 = d.inv_w1 = 0.f; d.part = nullptr; d.ticket = nullptr; d.cols = 0; }
     if (d.dst && (!d.part || !d.ticket)) return (int)hipErrorInvalidValue;
     if (d.n_slabs_img > n_slabs) d.n_slabs_img = n_slabs;
     OptArgs oc = *o;

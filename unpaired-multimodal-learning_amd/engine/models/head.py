@@ -215,9 +215,9 @@ class _HeadBase(nn.Module):
                     bind["m_proj"] = pk[0]
                     if len(pk) > 1:
                         bind["v_proj"] = pk[1]
+                if self._learnable_temp:
+                    self._bind_scale_state(optimizer, opt_name, dev, bind)
             eng.rebind(**bind)
-            if optimizer is not None and self._learnable_temp:
-                raise NotImplementedError("bias=True with learnable_temp: not wired (the reference never builds it)")
             self._engines[key] = eng
             return eng
         eng = umlh.HeadEngine(self.vision_model.num_features, self.shared_dim, self.num_classes,
@@ -239,19 +239,22 @@ class _HeadBase(nn.Module):
                 if v is not None:
                     bind["v_proj"] = v
             if self._learnable_temp:
-                # the kernels keep the two scales' moments packed as float[2]; expose them to the
-                # optimizer as per-parameter views so state_dict()/step() see the same storage
-                pk = getattr(optimizer, "_packed_scale_state", None)
-                if pk is None:
-                    pk = (torch.zeros(2, device=dev), torch.zeros(2, device=dev))
-                    optimizer._packed_scale_state = pk
-                    for j, p in enumerate((self.img_scale, self.txt_scale)):
-                        optimizer.state[p] = ({"momentum_buffer": pk[0][j]} if opt_name == "sgd" else
-                                              {"exp_avg": pk[0][j], "exp_avg_sq": pk[1][j]})
-                bind["m_scales"], bind["v_scales"] = pk
+                self._bind_scale_state(optimizer, opt_name, dev, bind)
         eng.rebind(**bind)
         self._engines[key] = eng
         return eng
+
+    def _bind_scale_state(self, optimizer, opt_name, dev, bind):
+        """Learnable logit scales (head.py:69-70): the kernels keep the two scales' moments packed as float[2]; expose them to
+        the optimizer as per-parameter views so state_dict()/step() see the same storage."""
+        pk = getattr(optimizer, "_packed_scale_state", None)
+        if pk is None:
+            pk = (torch.zeros(2, device=dev), torch.zeros(2, device=dev))
+            optimizer._packed_scale_state = pk
+            for j, p in enumerate((self.img_scale, self.txt_scale)):
+                optimizer.state[p] = ({"momentum_buffer": pk[0][j]} if opt_name == "sgd" else
+                                      {"exp_avg": pk[0][j], "exp_avg_sq": pk[1][j]})
+        bind["m_scales"], bind["v_scales"] = pk
 
     def _infer_engine(self, rows):
         for eng in self._engines.values():     # logits / eval always run the exact fp32 kernels

@@ -216,11 +216,8 @@ def train(model, image_loader, text_loader, val_loader, test_loader, optimizer, 
     # per-step gradient diagnostics (finetune.py:190-191,203-206): the reference computes them on every
     # step; here they cost ~2.5 us per step, so they are on when a logger asks for them (or on request)
     want_diag = bool(diagnostics) if diagnostics is not None else logger is not None
-    if want_diag and getattr(model, "_bias", False):
-        # the packed [weight | bias | padding] tensor would count its padding columns as sign agreements and fold the bias into
-        # the norms: the reference's diagnostics are over head.weight only (finetune.py:190-191)
-        print("=> gradient diagnostics are not formed for heads with bias (logged as zeros)")
-        want_diag = False
+    # (heads with bias: the engine restricts them to the weight columns of the packed [weight | bias | padding] rows -- the
+    # reference's diagnostics are over head.weight only, finetune.py:190-191)
     engine.enable_diagnostics(want_diag)
     scalars = torch.zeros(max_iters, umlh.N_SCALARS, dtype=torch.float32, device=dev)
     no_improve = 0

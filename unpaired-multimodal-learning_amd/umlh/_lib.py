@@ -21,7 +21,7 @@ N_CORE_SCALARS = 8
 N_SCALARS = 12
 
 SOURCES = ["umlh_p2p.hip", "umlh_kernels_f32.hip", "umlh_kernels_bf16.hip", "umlh_kernels_micro.hip", "umlh_kernels_seq.hip", "umlh_kernels_enc.hip", "umlh_api.cpp", "umlh_encoder.cpp"]
-EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_freeze_proj_row", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
+EXPORTS = ["umlh_last_error", "umlh_version", "umlh_enable_diagnostics", "umlh_set_diagnostic_columns", "umlh_freeze_proj_row", "umlh_workspace_bytes", "umlh_create", "umlh_destroy", "umlh_bind",
            "umlh_zero_shot_init", "umlh_logits", "umlh_train_step", "umlh_grad_step", "umlh_grad_buffer",
            "umlh_apply_update", "umlh_eval_batch", "umlh_eval_rows", "umlh_project", "umlh_optimizer_step",
            "umlh_profile_enable", "umlh_profile_read", "umlh_to_bf16",
@@ -133,6 +133,7 @@ def load_library():
     lib.umlh_destroy.argtypes = [vp]
     lib.umlh_bind.argtypes = [vp, C.POINTER(Buffers)]
     lib.umlh_enable_diagnostics.argtypes = [vp, C.c_int32]
+    lib.umlh_set_diagnostic_columns.argtypes = [vp, C.c_int32]
     lib.umlh_freeze_proj_row.argtypes = [vp, C.c_int32]
     lib.umlh_eval_rows.argtypes = [vp, C.POINTER(Batch), vp, vp]
     i32, f32 = C.c_int32, C.c_float

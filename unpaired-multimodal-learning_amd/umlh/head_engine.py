@@ -237,7 +237,10 @@ class HeadEngine:
         return out
 
     def enable_diagnostics(self, on: bool = True) -> None:
-        """Per-step gradient diagnostics (S_GRAD_* scalars; see ``grad_diagnostics``) on/off."""
+        """Per-step gradient diagnostics (S_GRAD_* scalars; see ``grad_diagnostics``) on/off.  For a head with bias they cover
+        the weight columns only, as the reference's do (finetune.py:190-191: ``model.head.weight``)."""
+        if on and self.bias_from is not None:
+            check(self.lib.umlh_set_diagnostic_columns(self.handle, int(self._from_txt)), "umlh_set_diagnostic_columns")
         check(self.lib.umlh_enable_diagnostics(self.handle, 1 if on else 0), "umlh_enable_diagnostics")
 
     def train_step(self, img: Optional[RowBatch], txt: Optional[RowBatch], lr: float, step: int,
