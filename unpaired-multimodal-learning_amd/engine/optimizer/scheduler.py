@@ -55,13 +55,49 @@ class StepLR:
         return list(self._last_lr)
 
     def lr_table(self, n, start=None):
-        """lr_at(k0 .. k0+n-1) as a list of Python floats (doubles: ``Hyper.lr`` / ``GroupItem.lr`` take doubles).  Every entry
-        is formed by the SAME expression as ``lr_at`` -- the cosine tail with ``math.cos`` per element, not a vectorised
-        ``numpy.cos``, whose last bit can differ -- so a blockwise run (lr_table) and a stepwise run (lr_at) see bit-identical
-        learning rates (tests/test_host_api_cpu.py pins it over a 12 800-step schedule)."""
+        """lr_at(k0 .. k0+n-1) as a list of Python floats (doubles: ``Hyper.lr`` / ``GroupItem.lr`` take doubles), bit-identical
+        to ``lr_at`` entry by entry (tests/test_host_api_cpu.py pins it over a 12 800-step schedule): the base-independent
+        factor of the tail -- ``1 + math.cos(pi t / max_iter)`` resp. ``1 - t / max_iter``, formed per element with the SAME
+        scalar expression as ``lr_at``, never a vectorised ``numpy.cos`` whose last bit can differ -- is cached per (kind,
+        max_iter) and shared by every head of a sweep; what remains per call, ``base * factor / 2`` resp. ``base * factor`` and
+        the warm-up's ``base * k / warmup_iter``, are single IEEE double operations that numpy performs exactly as Python does."""
+        import numpy as np
         k0 = self.last_epoch if start is None else start
         base = self.base_lrs[0]
-        return [self.lr_at(k, base) for k in range(k0, k0 + n)]
+        out = np.empty(n, dtype=np.float64)
+        nw = min(max(self.warmup_iter - k0, 0), n)                 # leading entries still inside the warm-up
+        if nw:
+            if self.warmup_type == "constant":
+                out[:nw] = float(self.warmup_lr)
+            else:
+                out[:nw] = base * np.arange(k0, k0 + nw, dtype=np.float64) / self.warmup_iter
+                if k0 == 0:
+                    out[0] = float(self.warmup_lr)
+        if nw < n:
+            t0 = k0 + nw - self.warmup_iter
+            f = _tail_factors(self.kind, self.max_iter, t0 + (n - nw))[t0:t0 + (n - nw)]
+            out[nw:] = base * f / 2.0 if self.kind == "cosine" else base * f
+        return out.tolist()
+
+
+_FACTORS = {}
+
+
+def _tail_factors(kind, max_iter, upto):
+    """factor[t] of the post-warm-up schedule for t < upto (grown on demand, shared between schedulers)."""
+    import numpy as np
+    key = (kind, max_iter)
+    f = _FACTORS.get(key)
+    if f is None or len(f) < upto:
+        have = 0 if f is None else len(f)
+        size = max(upto, 2 * have, 1024)
+        if kind == "cosine":
+            ext = [1.0 + math.cos(math.pi * t / max_iter) for t in range(have, size)]
+        else:
+            ext = [1.0 - t / max_iter for t in range(have, size)]
+        f = np.concatenate([f, np.asarray(ext, dtype=np.float64)]) if have else np.asarray(ext, dtype=np.float64)
+        _FACTORS[key] = f
+    return f
 
 
 def build_lr_scheduler(optimizer, lr_scheduler, warmup_iter, max_iter, warmup_type=None, warmup_lr=None,
