@@ -784,7 +784,7 @@ __global__ __launch_bounds__(512) void fwd_ce_bf16_q(FwdArgsB a) {
                         ok = ok && (unsigned)(g4[f] >> 32) == a.epoch;
                     }
                     if (__all(ok)) break;
-                    if ((spin & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) bad = true;   // 2 s at 100 MHz
+                    if ((spin & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) bad = true;   // 50 ms at 100 MHz
                     __builtin_amdgcn_s_sleep(1);
                 }
                 gm[p] = __uint_as_float((unsigned)g4[0]); gs[p] = __uint_as_float((unsigned)g4[1]);
@@ -1434,8 +1434,13 @@ __global__ __launch_bounds__(512) void dw_bf16(DwArgsB g) {
 #define UMLH_STEP_DW_LDS DW_DMA_LDS_BYTES
 #endif
 struct StepShape { int nfwd, ndw, nupd, nfin;
-                   int lazy; };   // test switch (UMLH_STEP_LAZY=1): every 4th workgroup leaves its forward and dW home tasks alone,
+                   int lazy;      // test switch (UMLH_STEP_LAZY=1): every 4th workgroup leaves its forward and dW home tasks alone,
                                   // as if it had not been dispatched yet -- whoever needs them takes them (tasks_wait)
+                   int fs, fper; };   // home forward tile of workgroup b = (b % fs) * fper + b / fs  (fs = 0: tile b).  With fs = the
+                                  // number of K splits and fper tiles per split, the forward tiles of K range z run on the workgroups
+                                  // with b % fs == z -- under round-robin placement the XCD whose dW tiles (split z = b % nsplit) read
+                                  // those feature rows and that slice of dZ^T a few microseconds later: their loads find the lines in
+                                  // that XCD's L2.  Placement is a speed matter only (every load involved stays what it was).
 
 template <int CTW, int WC>
 __device__ __forceinline__ int step_update_task(const HeadFuse& hf, const DwGate& gate, const StepShape& sh, int u, int* sh_rc) {
@@ -1576,13 +1581,14 @@ __global__ __launch_bounds__(512) void step_bf16(StepArgs p) {
     const StepArgs* kp = (const StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();   // for the cold path: it reads the argument from there
     const int b_dw = p.sh.nfwd, b_upd = p.sh.nfwd + p.sh.ndw, b_fin = p.sh.nfwd + p.sh.ndw + p.sh.nupd;   // task ids: forward, dW, update, finalize
     const bool lazy = p.sh.lazy && (b & 3) == 1;
+    const int fb = (p.sh.fs > 0 && G >= p.sh.nfwd && b < p.sh.nfwd) ? (b % p.sh.fs) * p.sh.fper + b / p.sh.fs : b;   // home forward tile (StepShape)
     // all first home tasks are taken NOW, by four lanes of one instruction: the takes of the later phases cost nothing when
     // their turn comes, and nobody who waits for one of them finds it untaken while this workgroup is still in an earlier phase
     TakeHook hook = {ctl.epoch, ctl.epoch, sh_ctl + 4};       // (old == epoch reads as "not mine")
     if (threadIdx.x < 4) {
         const int k = (int)threadIdx.x;
         int t = -1;
-        if (k == 0 && !lazy && b < p.sh.nfwd) t = b;
+        if (k == 0 && !lazy && b < p.sh.nfwd) t = fb;
         if (k == 1 && !lazy && b < p.sh.ndw) t = b_dw + b;
         if (k == 2 && p.sh.nfin > 0 && b == G - 1) t = b_fin;
         if (k == 3 && b < p.sh.nupd) t = b_upd + b;
@@ -1591,7 +1597,7 @@ __global__ __launch_bounds__(512) void step_bf16(StepArgs p) {
     if (!lazy && b < p.sh.nfwd) {
         // the forward tile starts on its loads NOW and settles the four takes in front of its first barrier (TakeHook): the
         // round trip of the atomics (0.5-1 us when 256 workgroups start together) is off the step's critical path
-        step_fwd_task<CTW, WC>(p, b, smem_dyn, &hook);
+        step_fwd_task<CTW, WC>(p, fb, smem_dyn, &hook);
     } else {
         if (threadIdx.x < 4) sh_ctl[4 + threadIdx.x] = tag_older(hook.old, ctl.epoch) ? 1 : 0;
         __syncthreads();
@@ -1747,7 +1753,12 @@ int umlh_bf16_launch_step(const FwdArgsB* a, int ctw, int wc, int nfwd, const Dw
     DwArgsB ga = *g; ga.plain = 0;
     HeadFuse h;
     memset(&h, 0, sizeof(h));
-    StepShape shp = {nfwd, ndw, 0, 0, lazy};
+    StepShape shp = {nfwd, ndw, 0, 0, lazy, 0, 0};
+    {   // forward tiles of a K range on the workgroups of "its" XCD (StepShape::fs; UMLH_STEP_XCD=0: tile b on workgroup b)
+        static const bool xcd_map = [] { const char* e = getenv("UMLH_STEP_XCD"); return !(e && atoi(e) == 0); }();
+        const int per = ts > 0 && g->k_chunk % ts == 0 ? g->k_chunk / ts : 0;
+        if (xcd_map && splits > 1 && per > 0 && nfwd == per * splits && g->k_switch == g->nsplit1 * g->k_chunk) { shp.fs = splits; shp.fper = per; }
+    }
     if (hf) {
         h = *hf;
         const long long n4 = (long long)h.C * h.K / 4;

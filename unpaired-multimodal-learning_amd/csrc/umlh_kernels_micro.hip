@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void micro_steps_kernel(const UmlhMicroHead* _
                     if (__all(ok || !slot_live)) break;
                     if ((spin & 63u) == 63u) {
                         const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (st != 0u || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { bad = 1; break; }   // 2 s at 100 MHz
+                        if (st != 0u || __builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) { bad = 1; break; }   // 50 ms at 100 MHz (umlh_micro_status reports it)
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
