@@ -410,7 +410,7 @@ def main():
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
         if args.cfg3 and world == 1:
-            out["cfg3"] = measure_cfg3(torch, umlh, device)
+            out["cfg3"] = measure_cfg3(torch, umlh, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -12,6 +12,8 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $o/${tag}_bench_driver_args.log
 python bench.py --force-dp-path --no-cpu-baseline --no-fp32-leg > $o/${tag}_force_dp.log 2>&1; jl $o/${tag}_force_dp.log > $o/${tag}_bench_force_dp_c_loop.json
 UMLH_BF16_FUSE=0 python bench.py --no-cpu-baseline --no-fp32-leg 2>/dev/null | grep '^{' | tail -1 > $o/${tag}_bench_three_launches.json
 UMLH_BF16_FUSE=0 UMLH_BF16_DW=0 python bench.py --no-cpu-baseline --no-fp32-leg 2>/dev/null | grep '^{' | tail -1 > $o/${tag}_bench_three_launches_old_dw_tile.json
+UMLH_STEP_XCD=0 python bench.py --no-cpu-baseline --no-fp32-leg 2>/dev/null | grep '^{' | tail -1 > $o/${tag}_bench_identity_home_tiles.json
+python bench.py --no-cpu-baseline --no-fp32-leg --cfg3 2>/dev/null | grep '^{' | tail -1 > $o/${tag}_bench_with_cfg3_key.json
 UMLH_F32_FWD=1 python bench.py --precision fp32 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $o/${tag}_bench_fp32_lds_staged_fwd.json
 echo "bench legs done"
 cd /tmp && export TMPDIR=/tmp
@@ -39,4 +41,6 @@ python scripts/small_step_timing.py 32 fp32 4 > $o/${tag}_micro_step_timing.txt 
 python scripts/small_step_timing.py 32 bf16 4 >> $o/${tag}_micro_step_timing.txt 2>&1 || true
 python scripts/bench_multibench.py 2>/dev/null > $o/${tag}_multibench_step.txt || true
 python scripts/bench_configs.py 2>/dev/null > $o/${tag}_other_configs.txt || true
+python scripts/bench_farm.py --iters 1000 --workers 1 --grouped 2>/dev/null > $o/${tag}_farm.txt || true
+python scripts/bench_farm.py --iters 4000 --workers 1 --grouped 2>/dev/null >> $o/${tag}_farm.txt || true
 jl $o/${tag}_bench.json | cut -c1-400
