@@ -187,7 +187,7 @@ static bool make_layout(const umlh_config_t& c, Layout& L) {
     L.w32s = 0;
     if (c.precision == UMLH_PREC_FP32 && c.d_shared % 32 == 0) {
         int ctw = 0, wc = 0;
-        if (umlh_f32_fwd_config(c.num_classes, &ctw, &wc) > 0) L.w32s = take((long long)c.d_shared * 32 * ctw * wc);
+        if (umlh_f32_fwd_config(c.num_classes, &ctw, &wc) > 0) L.w32s = take((long long)c.d_shared * 32 * ctw * wc * 3 / 2);   // (x3: three bf16 planes = 1.5x the fp32 shadow)
     }
     // one-launch step (step_bf16): per task one done granule (u64) and one claim word (u32), then the status words
     L.ctl_tasks = L.max_blocks + 4096 + L.n_head / 2048 + 8;
@@ -1114,6 +1114,7 @@ static int forward_backward(umlh_handle_t h, const umlh_batch_t* img, const umlh
             HIPCHK(umlh_launch_w_shadow32(h->buf.w_head, ws(h, L.w32s), c.num_classes, c.d_shared, 32 * h->ctw * h->wc, st), "w_shadow32");
         h->shadow_fresh = false;
         fa.Ws = ws(h, L.w32s);
+        fa.x3 = umlh_f32_x3();
     }
     HIPCHK(umlh_f32_launch_fwd(&fa, h->ctw, h->wc, nb0 + nb1, st), "fwd_ce");
     mark(h, 2, st);

@@ -37,6 +37,17 @@ static inline int umlh_plain_stores() {
     return v;
 }
 
+// fp32 mode on the bf16 matrix pipe ("x3", round 3): every fp32 operand is split into three bf16 pieces, x = hi + mid + lo
+// (hi, mid by truncation -- each residual is exact in fp32 --, lo rounded to nearest), and a product x*w is formed as the six
+// piece products of order <= 2 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: every piece product is exact, the dropped terms are <= 2^-23 |x||w| -- the error of ONE fp32 rounding -- and
+// the 32x32x16 bf16 MFMA does in 32 cycles what the 32x32x2 fp32 MFMA does in 8 x 64.  UMLH_F32_X3=0 keeps the fp32 MFMA.
+static inline int umlh_f32_x3() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UMLH_F32_X3"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 // ---- one modality's rows as the forward kernel sees them ----
@@ -66,6 +77,7 @@ struct FwdArgs {
     const float* Ws;             // fp32 fragment-major shadow of W (w_shadow32_kernel), current; NULL = stage W through LDS
     int   dbg;                   // timing-only ablations of the streamed main loop (analysis build -DUMLH_ABLATIONS only): 21 no W refills, 22 no B reads, 23 both
     int   learn;                 // learnable_temp: also reduce sum_c p_c * raw_c (d loss / d scale); 0: the per-element fma is skipped
+    int   x3;                    // Ws holds the three bf16 piece planes of W (w_shadow_x3_kernel): fwd_ce_f32 MODE 3
 };
 
 // Elementwise tail of a dense layer of the MultiBench encoder, applied to v = alpha * sum (element (m, n), flat index
@@ -194,6 +206,7 @@ struct OptArgs {
     float bc2_sqrt;              // sqrt(1 - beta2^t)
     float beta1, one_m_beta1, beta2, one_m_beta2, eps, momentum, wd;
     int   plain;                 // 1 = plain stores of the updated state (default 0: write-through, see store_wt_f32)
+    int   x3;                    // the fp32 fragment-major shadow the update kernel refreshes is the three-plane bf16 split (umlh_f32_x3)
 };
 
 struct FinalizeArgs {
@@ -297,6 +310,18 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
+}
+// x3 split of two fp32 values into packed bf16 pairs {a, b}: hi and mid by truncation (v_perm_b32 of the raw bits), lo by RNE
+struct Split3 { unsigned hi, mid, lo; };
+__device__ __forceinline__ Split3 split3_pair(float a, float b) {
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    Split3 r;
+    r.hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                    // {a[31:16], b[31:16]}
+    const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u), rb = b - __builtin_bit_cast(float, ub & 0xffff0000u);
+    const unsigned va = __builtin_bit_cast(unsigned, ra), vb = __builtin_bit_cast(unsigned, rb);
+    r.mid = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    r.lo = pack_bf16x2(ra - __builtin_bit_cast(float, va & 0xffff0000u), rb - __builtin_bit_cast(float, vb & 0xffff0000u));
+    return r;
 }
 
 // --------------------------------------------------------------------------------------------------------------- //

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     constexpr int BUF = KT * (LDW + LDX);
     float* Ws0 = smem;                    // [2][KT][LDW] then [KT][LDX]
     constexpr int STG = 8 * CTW * 32 * 32;                                  // epilogue: dZ staging, 8 waves x [CTW*32][32] floats (aliases the tile buffers)
-    constexpr int XT2 = MODE == 2 ? TS * (16384 / TS + 4) : 0;              // MODE 2: the resident X block
+    constexpr int XT2 = MODE >= 2 ? TS * (16384 / TS + 4) : 0;              // MODE 2 / 3: the resident X block
     constexpr int TILE0 = 2 * BUF > STG ? 2 * BUF : STG;
     constexpr int TILE = TILE0 > XT2 ? TILE0 : XT2;
     float* red = smem + TILE;             // [WC][TS][4]
@@ -111,7 +111,95 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
     // runs alone.  Wave-uniform; the accumulators stay 0 and the epilogue masks them as before.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const bool wave_live = row0 + (wave_u / WC) * 32 < sg.rows && (wave_u % WC) * CTW * 32 < C;
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 3) {
+        // MODE 2's structure on the bf16 matrix pipe (umlh_f32_x3 in umlh_common.h): W arrives pre-split -- three bf16 piece planes
+        // per fragment, [K/16 chunk][CPAD/32 tile][3 planes][64 lanes][8 bf16], 3 KB per (chunk, tile) instead of 2 KB --, the
+        // wave splits its B fragment (8 floats of its sample row per chunk, read from the fp32 X block in LDS) in registers (44
+        // VALU operations per chunk, issued under the MFMAs), and a chunk of a class tile is six v_mfma_f32_32x32x16_bf16
+        // (192 cycles) instead of eight v_mfma_f32_32x32x2_f32 (512 cycles).  Same accumulator layout: the epilogue is shared.
+        typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        constexpr int XK = 16384 / TS;
+        constexpr int XLD = XK + 4;
+        constexpr int NPX2 = (TS * (XK / 4)) / 512;
+        constexpr int PD = 2;
+        float* Xt = smem;
+        const float* xs2[NPX2];
+#pragma unroll
+        for (int q = 0; q < NPX2; ++q) {
+            const int pp = tid + 512 * q;
+            const int rc = min(row0 + pp / (XK / 4), sg.rows - 1);
+            const int64_t rid = sg.feat_index ? sg.feat_index[rc] : (int64_t)rc;
+            xs2[q] = sg.feats + (size_t)rid * sg.ld + 4 * (pp % (XK / 4));
+        }
+        const u32x4s* wl = reinterpret_cast<const u32x4s*>(a.Ws) + (size_t)(wc * CTW) * 192 + lane;
+        const int nch = K / KT;
+        auto wfrag = [&](int c, int ct, int plane) -> u32x4s { return wl[((size_t)c * (CPAD / 32) + ct) * 192 + plane * 64]; };
+        u32x4s ring[PD][CTW][3];
+        if (wave_live) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d)
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) ring[d][ct][pl] = wfrag(min(d, nch - 1), ct, pl);
+        }
+        STAMP(1);
+        for (int kb0 = 0; kb0 < K; kb0 += XK) {
+            const int kbw = min(XK, K - kb0);
+            f32x4v xr[NPX2];
+#pragma unroll
+            for (int q = 0; q < NPX2; ++q) {
+                const int col = 4 * ((tid + 512 * q) % (XK / 4));
+                xr[q] = *reinterpret_cast<const f32x4v*>(xs2[q] + kb0 + min(col, kbw - 4) - col);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NPX2; ++q) {
+                const int pp = tid + 512 * q;
+                *reinterpret_cast<f32x4v*>(Xt + (pp / (XK / 4)) * XLD + 4 * (pp % (XK / 4))) = xr[q];
+            }
+            __syncthreads();
+            if (wave_live) {
+                const int c0 = kb0 / KT, ncb = kbw / KT;
+                const float* xrow = Xt + (ws * 32 + l31) * XLD + 8 * h;
+                for (int c = 0; c < ncb; c += PD) {
+#pragma unroll
+                    for (int d = 0; d < PD; ++d) {
+                        const f32x4v b0 = *reinterpret_cast<const f32x4v*>(xrow + (c + d) * KT);
+                        const f32x4v b1 = *reinterpret_cast<const f32x4v*>(xrow + (c + d) * KT + 4);
+                        u32x4s bh, bm, bl;
+                        { const Split3 s3 = split3_pair(b0[0], b0[1]); bh[0] = s3.hi; bm[0] = s3.mid; bl[0] = s3.lo; }
+                        { const Split3 s3 = split3_pair(b0[2], b0[3]); bh[1] = s3.hi; bm[1] = s3.mid; bl[1] = s3.lo; }
+                        { const Split3 s3 = split3_pair(b1[0], b1[1]); bh[2] = s3.hi; bm[2] = s3.mid; bl[2] = s3.lo; }
+                        { const Split3 s3 = split3_pair(b1[2], b1[3]); bh[3] = s3.hi; bm[3] = s3.mid; bl[3] = s3.lo; }
+                        const bf16x8 vbh = __builtin_bit_cast(bf16x8, bh), vbm = __builtin_bit_cast(bf16x8, bm), vbl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+                        for (int ct = 0; ct < CTW; ++ct) {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, ring[d][ct][0]), am = __builtin_bit_cast(bf16x8, ring[d][ct][1]);
+                            const bf16x8 al = __builtin_bit_cast(bf16x8, ring[d][ct][2]);
+                            // small terms first, the hi*hi product last
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vbh, acc[ct], 0, 0, 0);
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vbl, acc[ct], 0, 0, 0);
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, vbm, acc[ct], 0, 0, 0);
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, vbh, acc[ct], 0, 0, 0);
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vbm, acc[ct], 0, 0, 0);
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vbh, acc[ct], 0, 0, 0);
+                        }
+                        const int nxt = min(c0 + c + d + PD, nch - 1);
+#pragma unroll
+                        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) ring[d][ct][pl] = wfrag(nxt, ct, pl);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);            // B reads
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6 * CTW, 0);      // MFMAs (the split's VALU operations float between them)
+                        __builtin_amdgcn_sched_group_barrier(0x020, 3 * CTW, 0);      // VMEM reads
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    } else if constexpr (MODE == 2) {
         constexpr int XK = 16384 / TS;                      // K-block of the X rows resident in LDS: TS x XK floats = 64 KB
         constexpr int XLD = XK + 4;                         // row stride (floats): an odd multiple of 16 B -> the b128 reads of 16 rows hit 16 slots
         constexpr int NPX2 = (TS * (XK / 4)) / 512;         // 16-B pieces of an X block per thread
@@ -1236,7 +1324,22 @@ __global__ __launch_bounds__(256) void head_step_kernel(const float* __restrict_
         if (o.plain) *reinterpret_cast<u32x2s*>(shadow + piece * 8 + (k & 7)) = w;
         else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(shadow + piece * 8 + (k & 7)), "v"(w) : "memory");
     }
-    if (shadow32 != nullptr) {             // fp32 fragment-major shadow of the new weights (w_shadow32_kernel's layout): 4 floats = half a lane slot
+    if (shadow32 != nullptr && o.x3) {     // three-plane bf16 split of the new weights (w_shadow_x3_kernel's layout): 4 values = half a lane slot per plane
+        const int cls = (int)(i / K), k = (int)(i % K);
+        typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+        u32x2s hi, mid, lo;
+        { const Split3 s3 = split3_pair(p0[0], p0[1]); hi[0] = s3.hi; mid[0] = s3.mid; lo[0] = s3.lo; }
+        { const Split3 s3 = split3_pair(p0[2], p0[3]); hi[1] = s3.hi; mid[1] = s3.mid; lo[1] = s3.lo; }
+        unsigned short* base = reinterpret_cast<unsigned short*>(shadow32) +
+                               (((long long)(k >> 4) * (cpad / 32) + (cls >> 5)) * 192 + (cls & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+        if (o.plain) {
+            *reinterpret_cast<u32x2s*>(base) = hi; *reinterpret_cast<u32x2s*>(base + 512) = mid; *reinterpret_cast<u32x2s*>(base + 1024) = lo;
+        } else {
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(base), "v"(hi) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(base + 512), "v"(mid) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(base + 1024), "v"(lo) : "memory");
+        }
+    } else if (shadow32 != nullptr) {      // fp32 fragment-major shadow of the new weights (w_shadow32_kernel's layout): 4 floats = half a lane slot
         const int cls = (int)(i / K), k = (int)(i % K);
         const long long piece = ((long long)(k >> 4) * (cpad / 32) + (cls >> 5)) * 64 + (cls & 31) + 32 * ((k >> 3) & 1);
         store_out_f32x4(shadow32 + piece * 8 + (k & 7), p0, o.plain);
@@ -1344,6 +1447,28 @@ __global__ __launch_bounds__(256) void w_shadow32_kernel(const float* __restrict
     *reinterpret_cast<f32x4v*>(dst + q * 4) = v;
 }
 
+// The same fragments as three bf16 piece planes (umlh_f32_x3, umlh_common.h): [K/16 chunk][CPAD/32 tile][plane][64 lanes][8 bf16];
+// one thread per half lane slot (4 values).
+__global__ __launch_bounds__(256) void w_shadow_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int C, int K, int cpad) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int tiles = cpad / 32;
+    const long long total = (long long)(K / 16) * tiles * 128;
+    if (q >= total) return;
+    const int half = (int)(q & 1), lane = (int)((q >> 1) & 63);
+    const int tile = (int)((q >> 7) % tiles), c = (int)((q >> 7) / tiles);
+    const int cls = tile * 32 + (lane & 31);
+    f32x4v v = {0.f, 0.f, 0.f, 0.f};
+    if (cls < C) v = *reinterpret_cast<const f32x4v*>(w + (size_t)cls * K + c * 16 + 8 * (lane >> 5) + 4 * half);
+    typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+    u32x2s hi, mid, lo;
+    { const Split3 s3 = split3_pair(v[0], v[1]); hi[0] = s3.hi; mid[0] = s3.mid; lo[0] = s3.lo; }
+    { const Split3 s3 = split3_pair(v[2], v[3]); hi[1] = s3.hi; mid[1] = s3.mid; lo[1] = s3.lo; }
+    unsigned short* base = dst + (((long long)c * tiles + tile) * 192 + lane) * 8 + 4 * half;
+    *reinterpret_cast<u32x2s*>(base) = hi;
+    *reinterpret_cast<u32x2s*>(base + 512) = mid;
+    *reinterpret_cast<u32x2s*>(base + 1024) = lo;
+}
+
 // --------------------------------------------------------------------------- //
 // launchers (called from umlh_api.cpp)
 // --------------------------------------------------------------------------- //
@@ -1352,6 +1477,10 @@ extern "C" {
 int umlh_launch_w_shadow32(const float* w, float* dst, int C, int K, int cpad, hipStream_t stream) {
     if (K % 16 != 0 || cpad % 32 != 0) return (int)hipErrorInvalidValue;
     const long long total = (long long)(K / 16) * (cpad / 32) * 128;
+    if (umlh_f32_x3()) {       // (dst holds 1.5x the fp32 shadow's bytes: umlh_api.cpp Layout::w32s)
+        hipLaunchKernelGGL(w_shadow_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, (unsigned short*)dst, C, K, cpad);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(w_shadow32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, dst, C, K, cpad);
     return (int)hipGetLastError();
 }
@@ -1372,7 +1501,7 @@ int umlh_f32_fwd_config(int C, int* ctw, int* wc) {
 static size_t fwd_smem_bytes(int ctw, int wc, int mode) {
     int ws = 8 / wc, cpad = 32 * ctw * wc, ts = 32 * ws;
     size_t tile = (size_t)2 * KT * (cpad + 4 + ts + 4), stg = (size_t)8 * ctw * 32 * 32;   // (the epilogue's dZ staging aliases the tile buffers)
-    size_t xt2 = mode == 2 ? (size_t)ts * (16384 / ts + 4) : 0;
+    size_t xt2 = mode >= 2 ? (size_t)ts * (16384 / ts + 4) : 0;
     if (stg > tile) tile = stg;
     if (xt2 > tile) tile = xt2;
     return sizeof(float) * (tile + (size_t)(wc * ts * 4 + ws * 4 + 16));
@@ -1394,7 +1523,7 @@ static size_t fwd_smem_bytes(int ctw, int wc, int mode) {
         hipLaunchKernelGGL((fwd_ce_f32<CT, W, F>), dim3(grid), dim3(512), sm, stream, c_);          \
         return (int)hipGetLastError();                                                              \
     }
-#define FWD_CASE(CT, W) FWD_CASE_F(CT, W, 2) FWD_CASE_F(CT, W, 1) FWD_CASE_F(CT, W, 0)
+#define FWD_CASE(CT, W) FWD_CASE_F(CT, W, 3) FWD_CASE_F(CT, W, 2) FWD_CASE_F(CT, W, 1) FWD_CASE_F(CT, W, 0)
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1406,7 +1535,7 @@ int umlh_f32_launch_fwd(const FwdArgs* a, int ctw, int wc, int grid, hipStream_t
     // MODE 2 (W streamed from the fragment-major shadow): the caller keeps the shadow current (umlh_launch_w_shadow32 /
     // the update kernel) and passes it in a->Ws; UMLH_F32_FWD=1 keeps the LDS-staged kernel for A/B timing
     static const bool no_stream = [] { const char* e = getenv("UMLH_F32_FWD"); return e && atoi(e) == 1; }();
-    const int mode = !fast ? 0 : ((a->Ws != nullptr && a->K % (2 * KT) == 0 && !no_stream) ? 2 : 1);
+    const int mode = !fast ? 0 : ((a->Ws != nullptr && a->K % (2 * KT) == 0 && !no_stream) ? (a->x3 ? 3 : 2) : 1);
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(1, 8) FWD_CASE(2, 8) FWD_CASE(4, 8)
     return (int)hipErrorInvalidValue;
 }
@@ -1516,6 +1645,7 @@ int umlh_launch_head_step(const float* slabs, int n_slabs, long long slab_stride
     if (d.n_slabs_img > n_slabs) d.n_slabs_img = n_slabs;
     OptArgs oc = *o;
     oc.plain = umlh_plain_stores();
+    oc.x3 = umlh_f32_x3();
     hipLaunchKernelGGL(head_step_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n_slabs, slab_stride, C, K, p, m, v, oc,
                        (unsigned short*)shadow, cpad, *f, grad_out, d, shadow32);
     return (int)hipGetLastError();
