@@ -992,6 +992,182 @@ __global__ __launch_bounds__(256) void dw_f32(GemmArgs g) {
 }
 
 // --------------------------------------------------------------------------- //
+// dw_f32x3: dw_f32's product (same GemmArgs contract, same 128 x 128 tile, same split-K / modality rules) on the bf16 matrix
+// pipe: fp32 operands split three ways, six piece products per product (umlh_f32_x3, umlh_common.h).
+//   * EIGHT waves (2 x 4, 64 x 32 outputs each): with one wave per SIMD (dw_f32's four) the split's VALU work and the MFMAs of
+//     the same wave did not overlap -- 352 VALU operations next to 48 MFMAs per chunk ran 84 -> 69 us, and splitting at staging
+//     time, finer interleaving and a second register set for earlier prefetch (all built, all parity-clean) stayed at 60-67 us:
+//     the sum of the two instruction streams, not their maximum.  Two waves per SIMD overlap them in hardware.
+//   * the staging SPLITS: a thread splits the 16-byte pieces it has loaded (2 A pieces + 2 B pieces per chunk) and writes three
+//     bf16 planes per operand -- every element is split once per workgroup, not once per wave that multiplies it.
+//       A planes: [128 rows][32 k] bf16, row stride 80 B (an odd multiple of 16 B: the b128 fragment reads of 16 rows hit 16
+//                 different slots); a lane's 16 k of the chunk are two groups of 8 = the k-slice of one
+//                 v_mfma_f32_32x32x16_bf16 (lane half h holds k = 16h + 8g .. + 8 of group g in both operands)
+//       B planes: [32 k][128 n] bf16 as the rows arrive (no transposing scalar stores), 16-byte chunk ch of k-row r stored at
+//                 ch ^ (((r & 3) << 2) | ((r >> 2) & 3)); fragments by ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane
+//                 group, conflict-free: dw_bf16's recipe)
+//   * per chunk (32 k) and wave: 2 groups x (6 A reads + 6 B reads) and 2 x 12 MFMAs; chunk c+1 is staged from registers while
+//     chunk c multiplies, chunk c+2 is requested right after -- a barrier per chunk.
+// --------------------------------------------------------------------------- //
+constexpr int X3_ARS = 80, X3_APL = 128 * X3_ARS, X3_BPL = 32 * 256, X3_BUF = 3 * X3_APL + 3 * X3_BPL;   // bytes per A row / A plane / B plane / buffer
+constexpr size_t DW_SMEM_X3 = 2 * (size_t)X3_BUF + sizeof(int) * DWKIDS;
+__global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
+    typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+    unsigned char* const lds = reinterpret_cast<unsigned char*>(dw_smem);
+    int* const kid = reinterpret_cast<int*>(lds + 2 * X3_BUF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, l31 = lane & 31;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int nsplit = (int)g.slab_count, z = blockIdx.x % nsplit, tile = blockIdx.x / nsplit, ntx = (g.N + 127) / 128;
+    const int m0 = (tile / ntx) * 128, n0 = (tile % ntx) * 128;
+    int kb = z * g.k_chunk, ke = min(g.K, kb + g.k_chunk);
+    if (g.nsplit1 > 0) {                                  // modality-aligned split-K
+        if (z < g.nsplit1) ke = min(g.k_switch, kb + g.k_chunk);
+        else { kb = g.k_switch + (z - g.nsplit1) * g.k_chunk; ke = min(g.K, kb + g.k_chunk); }
+    }
+    auto kvalid = [&](int k) -> bool { return k < g.k_switch ? (k < g.k_valid1) : (k - g.k_switch < g.k_valid2); };
+    for (int i = tid; i < ke - kb; i += 512) {            // gathered row id of every reduction row of this split; -1 = masked
+        const int k = kb + i;
+        int rid = -1;
+        if (kvalid(k)) {
+            if (k < g.k_switch) rid = g.k_rows ? (int)g.k_rows[k] : k;
+            else { const int kl = k - g.k_switch; rid = g.k_rows2 ? (int)g.k_rows2[kl] : kl; }
+        }
+        kid[i] = rid;
+    }
+    __syncthreads();
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // A pieces (2 per thread): row ar + 64q of the tile, k columns 4*akq .. +3 of the chunk; B pieces (2 per thread): reduction
+    // row bk of the chunk, columns 4*bnq + 64q .. +3 of the tile
+    const int ar = tid >> 3, akq = tid & 7;
+    const int bk = tid & 31, bnq = tid >> 5;
+    const float* a_row[2];
+    int b_col[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        a_row[q] = g.A + (size_t)min(m0 + ar + 64 * q, g.M - 1) * g.lda;
+        b_col[q] = min(n0 + 4 * bnq + 64 * q, g.N - 4);
+    }
+    f32x4v areg[2], breg[2];
+    int a_k = 0;
+    bool b_ok = false;
+    auto gload = [&](int k0) {
+        a_k = k0 + 4 * akq;
+        const int kc = min(a_k, g.lda - 4);               // (only reduction indices >= K are ever clamped: masked below)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) areg[q] = *reinterpret_cast<const f32x4v*>(a_row[q] + kc);
+        const int k = k0 + bk;
+        const int rid = kid[min(k, ke - 1) - kb];
+        b_ok = (k < ke) & (rid >= 0);
+        const bool s2 = k >= g.k_switch;
+        const float* row = (s2 ? g.B2 : g.B) + (size_t)max(rid, 0) * (s2 ? g.ldb2 : g.ldb);
+        const float* br = b_ok ? row : g.B;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) breg[q] = *reinterpret_cast<const f32x4v*>(br + b_col[q]);
+    };
+    const int a_wr = ar * X3_ARS + 8 * akq;                                  // + 64 q * X3_ARS
+    const int b_sw = ((bk & 3) << 2) | ((bk >> 2) & 3);
+    const int b_wr = 3 * X3_APL + bk * 256 + 8 * (bnq & 1);                   // + (((bnq >> 1) + 8 q) ^ b_sw) * 16
+    auto stage = [&](int buf) {                           // split the four pieces in registers, three planes each
+        unsigned char* base = lds + buf * X3_BUF;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4v v = areg[q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = a_k + j;
+                const bool first = k < g.k_switch;
+                const bool ok = (k < ke) & ((first ? k : k - g.k_switch) < (first ? g.k_valid1 : g.k_valid2));
+                v[j] = ok ? v[j] : 0.f;
+            }
+            const Split3 s0 = split3_pair(v[0], v[1]), s1 = split3_pair(v[2], v[3]);
+            unsigned char* d = base + a_wr + 64 * q * X3_ARS;
+            *reinterpret_cast<u32x2s*>(d) = u32x2s{s0.hi, s1.hi};
+            *reinterpret_cast<u32x2s*>(d + X3_APL) = u32x2s{s0.mid, s1.mid};
+            *reinterpret_cast<u32x2s*>(d + 2 * X3_APL) = u32x2s{s0.lo, s1.lo};
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4v v = breg[q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = b_ok ? v[j] : 0.f;
+            const Split3 s0 = split3_pair(v[0], v[1]), s1 = split3_pair(v[2], v[3]);
+            unsigned char* d = base + b_wr + ((((bnq >> 1) + 8 * q) ^ b_sw) << 4);
+            *reinterpret_cast<u32x2s*>(d) = u32x2s{s0.hi, s1.hi};
+            *reinterpret_cast<u32x2s*>(d + X3_BPL) = u32x2s{s0.mid, s1.mid};
+            *reinterpret_cast<u32x2s*>(d + 2 * X3_BPL) = u32x2s{s0.lo, s1.lo};
+        }
+    };
+    // fragment addresses
+    const int a_rd = (wm * 64 + l31) * X3_ARS + 32 * h;                       // + i * 32 * X3_ARS + 16 * g + plane * X3_APL
+    const int b_ch = wn * 4 + (g16 & 1) * 2 + (p4 >> 1);                     // 16-byte chunk of this lane's 4 columns
+    const int b_rd = 3 * X3_APL + (16 * h + q4) * 256 + 8 * (p4 & 1);         // + (8 g + 4 hi) * 256 + (chunk ^ swizzle) * 16 + plane * X3_BPL
+    if (kb < ke) {
+        gload(kb);
+        stage(0);
+        if (kb + DWKC < ke) gload(kb + DWKC);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += DWKC) {
+        const unsigned char* base = lds + buf * X3_BUF;
+        const bool st1 = k0 + DWKC < ke, ld2 = k0 + 2 * DWKC < ke;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            bf16x8 A[2][3], B[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) A[i][pl] = *reinterpret_cast<const bf16x8*>(base + pl * X3_APL + a_rd + i * 32 * X3_ARS + 16 * g2);
+                const unsigned char* r0 = base + pl * X3_BPL + b_rd + 8 * g2 * 256;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + ((b_ch ^ ((q4 << 2) | ((2 * g2) & 3))) << 4)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * 256 + ((b_ch ^ ((q4 << 2) | ((2 * g2 + 1) & 3))) << 4)));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                B[pl] = __builtin_bit_cast(bf16x8, v);
+            }
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+#pragma unroll
+            for (int pd = 0; pd < 6; ++pd)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][PA[pd]], B[PB[pd]], acc[i], 0, 0, 0);
+            if (g2 == 0 && st1) stage(buf ^ 1);           // chunk c+1 (in registers) -> the other buffer, under the MFMAs above and the partner wave's
+        }
+        if (ld2) gload(k0 + 2 * DWKC);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = g.out + (size_t)z * g.slab_stride;
+    const float alpha = g.alpha * (g.alpha_ptr ? *g.alpha_ptr : 1.f);
+    // slab tile through the (free) LDS, wave-private [64 rows][32 columns]: a lane stores 16 B of one row
+    float* stg = dw_smem + wave * (64 * 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) stg[(i * 32 + acc_row(e, h)) * 32 + l31] = acc[i][e] * alpha;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nq = n0 + wn * 32 + 4 * (lane & 7);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int m = m0 + wm * 64 + row;
+        const f32x4v v = *reinterpret_cast<const f32x4v*>(stg + row * 32 + 4 * (lane & 7));
+        if (m < g.M && nq < g.N) store_out_f32x4(out + (size_t)m * g.ldo + nq, v, g.plain);
+    }
+}
+
+// --------------------------------------------------------------------------- //
 // gemm_enc: the dense layers of the MultiBench encoder (no row gathers).  Same contract as gemm_f32 with a 64x64 tile,
 // but the K range is staged 64 reduction rows at a time and the NEXT 64 are already in flight while a chunk is multiplied:
 // these GEMMs are short (K = 40 .. 300, or a split-K range of 64-128 rows of a 1600 / 2048 long reduction) and tiny, so
@@ -1560,13 +1736,15 @@ int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStrea
         if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
         if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ULL)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_f32x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM_X3);
             if (e != hipSuccess) return (int)e;
             attr_done.fetch_or(1ULL << (dev & 63), std::memory_order_release);
         }
         GemmArgs a = *g;
         a.slab_count = splits;
         a.plain = umlh_plain_stores();
-        hipLaunchKernelGGL(dw_f32, dim3(((g->N + 127) / 128) * ((g->M + 127) / 128) * splits), dim3(256), DW_SMEM, stream, a);
+        if (umlh_f32_x3()) hipLaunchKernelGGL(dw_f32x3, dim3(((g->N + 127) / 128) * ((g->M + 127) / 128) * splits), dim3(512), DW_SMEM_X3, stream, a);
+        else hipLaunchKernelGGL(dw_f32, dim3(((g->N + 127) / 128) * ((g->M + 127) / 128) * splits), dim3(256), DW_SMEM, stream, a);
         return (int)hipGetLastError();
     }
     // 64x64 tiles when the 128x128 grid would leave most of the 256 CUs with a single 4-wave workgroup
