@@ -334,6 +334,14 @@ def main():
                 "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
                 "kernel_ms_source": "HIP events on the step's stream, raw intervals, mean of %d instrumented steps" % nprof,
                 "step_frac_of_mfma_roof": round((sum(flops.values()) / (PEAK[precision] * 1e12)) / (dt / steps), 4)}
+        if precision == "fp32":
+            x3 = os.environ.get("UMLH_F32_X3", "1") != "0"
+            roof["arith"] = ("fp32 operands split three ways into bf16 pieces, six v_mfma_f32_32x32x16_bf16 piece products per product, fp32 "
+                             "accumulation (UMLH_F32_X3=1, the default): 'achieved' counts the fp32 products once, against the fp32 MFMA roof; "
+                             "'issued_frac_of_bf16_roof' counts the six bf16 MFMAs against the bf16 roof") if x3 else "v_mfma_f32_32x32x2_f32 (UMLH_F32_X3=0)"
+            if x3:
+                roof["issued_frac_of_bf16_roof"] = round(6.0 * achieved / PEAK["bf16"], 4)
+                roof["step_issued_frac_of_bf16_roof"] = round(6.0 * (sum(flops.values()) / (PEAK["bf16"] * 1e12)) / (dt / steps), 4)
         if "proj_bwd" in acc:
             # cfg2 has no img_proj: the proj_bwd interval holds NO kernel, so it reads what one pair of event markers costs on
             # this stream; every kernel interval above carries about half of it (rocprofv3's trace of the same kernels:
@@ -363,7 +371,9 @@ def main():
         roofline.update({"fp32_value": round(other["value"], 1), "fp32_ms_per_step": round(other["ms_per_step"], 4),
                          "fp32_kernel": other["roofline"]["kernel"], "fp32_achieved": other["roofline"]["achieved"],
                          "fp32_peak": PEAK["fp32"], "fp32_frac": other["roofline"]["frac"],
-                         "fp32_step_frac_of_mfma_roof": other["roofline"]["step_frac_of_mfma_roof"]})
+                         "fp32_step_frac_of_mfma_roof": other["roofline"]["step_frac_of_mfma_roof"],
+                         "fp32_arith": other["roofline"].get("arith"),
+                         "fp32_step_issued_frac_of_bf16_roof": other["roofline"].get("step_issued_frac_of_bf16_roof")})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

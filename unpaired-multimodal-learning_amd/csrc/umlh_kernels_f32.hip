@@ -1061,8 +1061,14 @@ __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
     f32x4v areg[2], breg[2];
     int a_k = 0;
     bool b_ok = false;
+    bool chunk_full = false;                              // every reduction row of the chunk in the registers is valid: no masks (uniform)
     auto gload = [&](int k0) {
         a_k = k0 + 4 * akq;
+        {   // rows k0 .. k0 + 31 all valid?  (one modality, inside its valid count and inside the split)
+            const bool first = k0 < g.k_switch;
+            const int last = k0 + DWKC - 1;
+            chunk_full = last < ke && (first ? (last < g.k_switch && last < g.k_valid1) : (last - g.k_switch < g.k_valid2));
+        }
         const int kc = min(a_k, g.lda - 4);               // (only reduction indices >= K are ever clamped: masked below)
 #pragma unroll
         for (int q = 0; q < 2; ++q) areg[q] = *reinterpret_cast<const f32x4v*>(a_row[q] + kc);
@@ -1083,12 +1089,14 @@ __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             f32x4v v = areg[q];
+            if (!chunk_full) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = a_k + j;
-                const bool first = k < g.k_switch;
-                const bool ok = (k < ke) & ((first ? k : k - g.k_switch) < (first ? g.k_valid1 : g.k_valid2));
-                v[j] = ok ? v[j] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int k = a_k + j;
+                    const bool first = k < g.k_switch;
+                    const bool ok = (k < ke) & ((first ? k : k - g.k_switch) < (first ? g.k_valid1 : g.k_valid2));
+                    v[j] = ok ? v[j] : 0.f;
+                }
             }
             const Split3 s0 = split3_pair(v[0], v[1]), s1 = split3_pair(v[2], v[3]);
             unsigned char* d = base + a_wr + 64 * q * X3_ARS;
@@ -1099,8 +1107,10 @@ __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             f32x4v v = breg[q];
+            if (!chunk_full) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = b_ok ? v[j] : 0.f;
+                for (int j = 0; j < 4; ++j) v[j] = b_ok ? v[j] : 0.f;
+            }
             const Split3 s0 = split3_pair(v[0], v[1]), s1 = split3_pair(v[2], v[3]);
             unsigned char* d = base + b_wr + ((((bnq >> 1) + 8 * q) ^ b_sw) << 4);
             *reinterpret_cast<u32x2s*>(d) = u32x2s{s0.hi, s1.hi};
