@@ -56,7 +56,10 @@ extern "C" {
 #define UMLH_OPT_ADAM  1   /* torch.optim.Adam(betas=(0.9,0.999))            optim.py:50-59 */
 #define UMLH_OPT_ADAMW 2   /* torch.optim.AdamW(betas=(0.9,0.999))           optim.py:61-71 */
 
-#define UMLH_PREC_FP32 0   /* f32-input MFMA (exact fp32 fma chain): the parity mode      */
+#define UMLH_PREC_FP32 0   /* fp32 operands, fp32 results: the parity mode (logits / loss 1e-4).  The fused step forms its products
+                            * from three-way bf16 splits of both operands on the bf16 MFMA (six exact piece products per product, fp32
+                            * accumulation; what is dropped is below one fp32 rounding) -- or, with UMLH_F32_X3=0 in the environment, on
+                            * the f32-input MFMA as in ABI <= 3.  umlh_logits / umlh_gemm_f32 always use the f32-input MFMA. */
 #define UMLH_PREC_BF16 1   /* bf16 operands, fp32 accumulate: the throughput mode         */
 
 typedef struct umlh_handle_s* umlh_handle_t;
