@@ -137,6 +137,7 @@ struct GemmArgs {
     int   nsplit1;
     int   slab_count;            // dw_f32 only: slabs of the launch (its grid is 1-D, split index fastest)
     Epilogue epi;                // applied by the kernel when the launch has ONE slab (a split-K launch leaves it to the reduce)
+    int   x3;                    // gemm_f32 (128 x 128 tiles): products on the bf16 matrix pipe from three-way splits (umlh_f32_x3)
 };
 
 // ---- bf16-mode argument blocks (kernels in umlh_kernels_bf16.hip, filled by umlh_api.cpp) ----

@@ -750,6 +750,33 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmArgs g) {
     auto compute = [&](int buf) {
         const float* As = As2[buf];
         const float* Bs = Bs2[buf];
+        if (TM == 2 && g.x3) {
+            // products on the bf16 matrix pipe (umlh_f32_x3): lane half h takes k = 8h .. 8h+7 of the chunk in both operands (8 scalar
+            // LDS reads per tile, as many as the fp32 form's), splits them three ways in registers and issues six
+            // v_mfma_f32_32x32x16_bf16 per output tile (192 cycles) where the fp32 form issues eight 64-cycle MFMAs
+            typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            u32x4s fa[TM][3], fb[TM][3];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const Split3 sa = split3_pair(As[(8 * h + 2 * pr) * GLD + wm * 32 * TM + t * 32 + l31], As[(8 * h + 2 * pr + 1) * GLD + wm * 32 * TM + t * 32 + l31]);
+                    fa[t][0][pr] = sa.hi; fa[t][1][pr] = sa.mid; fa[t][2][pr] = sa.lo;
+                    const Split3 sb = split3_pair(Bs[(8 * h + 2 * pr) * GLD + wn * 32 * TM + t * 32 + l31], Bs[(8 * h + 2 * pr + 1) * GLD + wn * 32 * TM + t * 32 + l31]);
+                    fb[t][0][pr] = sb.hi; fb[t][1][pr] = sb.mid; fb[t][2][pr] = sb.lo;
+                }
+            }
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};         // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+#pragma unroll
+            for (int pd = 0; pd < 6; ++pd)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][PA[pd]]), __builtin_bit_cast(bf16x8, fb[j][PB[pd]]), acc[i][j], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < KT / 2; ++kk) {
             const int krow = 2 * kk + h;
@@ -1769,6 +1796,7 @@ int umlh_f32_launch_gemm(const GemmArgs* g, int ta, int tb, int splits, hipStrea
     dim3 grid((g->N + t - 1) / t, (g->M + t - 1) / t, splits);
     GemmArgs c = *g;
     c.plain = umlh_plain_stores();
+    c.x3 = (tm == 2 && umlh_f32_x3()) ? 1 : 0;
 #define GEMM_CASE(A_, B_, T_) if (ta == A_ && tb == B_ && tm == T_) { hipLaunchKernelGGL((gemm_f32<A_, B_, T_>), grid, dim3(256), 0, stream, c); return (int)hipGetLastError(); }
     GEMM_CASE(0, 0, 1) GEMM_CASE(0, 0, 2) GEMM_CASE(0, 1, 1) GEMM_CASE(0, 1, 2) GEMM_CASE(1, 1, 1) GEMM_CASE(1, 1, 2)
     return (int)hipErrorInvalidValue;
