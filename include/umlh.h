@@ -58,7 +58,7 @@ extern "C" {
 
 #define UMLH_PREC_FP32 0   /* fp32 operands, fp32 results: the parity mode (logits / loss 1e-4).  The fused step forms its products
                             * from three-way bf16 splits of both operands on the bf16 MFMA (six exact piece products per product, fp32
-                            * accumulation; what is dropped is below one fp32 rounding) -- or, with UMLH_F32_X3=0 in the environment, on
+                            * accumulation; what is dropped is 2^-24 of a product rms, 2^-20 worst case: as accurate against float64 as the fp32 MFMA chain) -- or, with UMLH_F32_X3=0 in the environment, on
                             * the f32-input MFMA as in ABI <= 3.  umlh_logits / umlh_gemm_f32 always use the f32-input MFMA. */
 #define UMLH_PREC_BF16 1   /* bf16 operands, fp32 accumulate: the throughput mode         */
 

@@ -40,8 +40,10 @@ static inline int umlh_plain_stores() {
 // fp32 mode on the bf16 matrix pipe ("x3", round 3): every fp32 operand is split into three bf16 pieces, x = hi + mid + lo
 // (hi, mid by truncation -- each residual is exact in fp32 --, lo rounded to nearest), and a product x*w is formed as the six
 // piece products of order <= 2 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) on v_mfma_f32_32x32x16_bf16 with fp32
-// accumulation: every piece product is exact, the dropped terms are <= 2^-23 |x||w| -- the error of ONE fp32 rounding -- and
-// the 32x32x16 bf16 MFMA does in 32 cycles what the 32x32x2 fp32 MFMA does in 8 x 64.  UMLH_F32_X3=0 keeps the fp32 MFMA.
+// accumulation: every piece product is exact; the dropped terms (mid*lo, lo*mid, lo*lo) are below 2^-20 |x||w| in the worst
+// case and 2^-24 |x||w| rms (tests/test_x3_split_cpu.py) -- the size of the roundings an fp32 fma chain makes on its running sum:
+// against float64 the two forms are equally accurate (profiles/r03_x3_accuracy.txt) -- and the 32x32x16 bf16 MFMA does in 32
+// cycles what the 32x32x2 fp32 MFMA does in 8 x 64.  UMLH_F32_X3=0 keeps the fp32 MFMA.
 static inline int umlh_f32_x3() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("UMLH_F32_X3"); v = (e && e[0] == '0') ? 0 : 1; }
