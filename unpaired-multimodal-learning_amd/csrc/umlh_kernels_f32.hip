@@ -191,9 +191,14 @@ __global__ __launch_bounds__(512) void fwd_ce_f32(FwdArgs a) {
                         for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
                             for (int pl = 0; pl < 3; ++pl) ring[d][ct][pl] = wfrag(nxt, ct, pl);
+                        // a tile's three planes are requested again as soon as its six MFMAs are out (not after the chunk's 24): more of
+                        // the stream in flight per wave at the same register count
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);            // B reads
-                        __builtin_amdgcn_sched_group_barrier(0x008, 6 * CTW, 0);      // MFMAs (the split's VALU operations float between them)
-                        __builtin_amdgcn_sched_group_barrier(0x020, 3 * CTW, 0);      // VMEM reads
+#pragma unroll
+                        for (int ct = 0; ct < CTW; ++ct) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);        // this tile's MFMAs (the split's VALU operations float between them)
+                            __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);        // its refill
+                        }
                     }
                 }
             }
