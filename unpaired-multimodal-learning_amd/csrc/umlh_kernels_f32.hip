@@ -1032,16 +1032,20 @@ __global__ __launch_bounds__(256) void dw_f32(GemmArgs g) {
 //     the sum of the two instruction streams, not their maximum.  Two waves per SIMD overlap them in hardware.
 //   * the staging SPLITS: a thread splits the 16-byte pieces it has loaded (2 A pieces + 2 B pieces per chunk) and writes three
 //     bf16 planes per operand -- every element is split once per workgroup, not once per wave that multiplies it.
-//       A planes: [128 rows][32 k] bf16, row stride 80 B (an odd multiple of 16 B: the b128 fragment reads of 16 rows hit 16
-//                 different slots); a lane's 16 k of the chunk are two groups of 8 = the k-slice of one
-//                 v_mfma_f32_32x32x16_bf16 (lane half h holds k = 16h + 8g .. + 8 of group g in both operands)
-//       B planes: [32 k][128 n] bf16 as the rows arrive (no transposing scalar stores), 16-byte chunk ch of k-row r stored at
-//                 ch ^ (((r & 3) << 2) | ((r >> 2) & 3)); fragments by ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane
-//                 group, conflict-free: dw_bf16's recipe)
+//       A planes: [128 rows][32 k] bf16 = 64-byte rows, 16-byte slot s of row r stored at s ^ ((r >> 2) & 3): the b128 fragment
+//                 reads (16-lane groups of rows {0-3, 12-15, 20-27} + 32i) and the 8-byte staging stores (16 lanes = 2 whole
+//                 rows = all 32 store banks) are both conflict-free (an 80-byte padded row was for the reads only: 28 % of the
+//                 LDS-active cycles were store conflicts, profiles/r03_fp32_x3_sq.txt); a lane's 16 k of the chunk are two
+//                 groups of 8 = the k-slice of one v_mfma_f32_32x32x16_bf16 (lane half h holds k = 16h + 8g .. + 8 of group g)
+//       B planes: [32 k][128 n] bf16 as the rows arrive (no transposing scalar stores); a thread holds 8 consecutive columns of
+//                 its k-row and stores 16 bytes per plane; 16-byte chunk ch of k-row r is stored at
+//                 ch ^ (((r & 3) << 2) | ((r >> 1) & 1) | (((r >> 2) & 1) << 1)): eight consecutive rows of one chunk hit eight
+//                 different 16-byte bank groups (b128 stores), and the ds_read_b64_tr_b16 fragments (4 k-rows x 16 columns per
+//                 16-lane group) stay conflict-free as in dw_bf16
 //   * per chunk (32 k) and wave: 2 groups x (6 A reads + 6 B reads) and 2 x 12 MFMAs; chunk c+1 is staged from registers while
 //     chunk c multiplies, chunk c+2 is requested right after -- a barrier per chunk.
 // --------------------------------------------------------------------------- //
-constexpr int X3_ARS = 80, X3_APL = 128 * X3_ARS, X3_BPL = 32 * 256, X3_BUF = 3 * X3_APL + 3 * X3_BPL;   // bytes per A row / A plane / B plane / buffer
+constexpr int X3_ARS = 64, X3_APL = 128 * X3_ARS, X3_BPL = 32 * 256, X3_BUF = 3 * X3_APL + 3 * X3_BPL;   // bytes per A row / A plane / B plane / buffer
 constexpr size_t DW_SMEM_X3 = 2 * (size_t)X3_BUF + sizeof(int) * DWKIDS;
 __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
     typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
@@ -1080,7 +1084,7 @@ __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     // A pieces (2 per thread): row ar + 64q of the tile, k columns 4*akq .. +3 of the chunk; B pieces (2 per thread): reduction
-    // row bk of the chunk, columns 4*bnq + 64q .. +3 of the tile
+    // row bk of the chunk, columns 8*bnq + 4q .. +3 of the tile (8 consecutive columns per thread)
     const int ar = tid >> 3, akq = tid & 7;
     const int bk = tid & 31, bnq = tid >> 5;
     const float* a_row[2];
@@ -1088,7 +1092,7 @@ __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         a_row[q] = g.A + (size_t)min(m0 + ar + 64 * q, g.M - 1) * g.lda;
-        b_col[q] = min(n0 + 4 * bnq + 64 * q, g.N - 4);
+        b_col[q] = min(n0 + 8 * bnq + 4 * q, g.N - 4);
     }
     f32x4v areg[2], breg[2];
     int a_k = 0;
@@ -1113,9 +1117,9 @@ __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) breg[q] = *reinterpret_cast<const f32x4v*>(br + b_col[q]);
     };
-    const int a_wr = ar * X3_ARS + 8 * akq;                                  // + 64 q * X3_ARS
-    const int b_sw = ((bk & 3) << 2) | ((bk >> 2) & 3);
-    const int b_wr = 3 * X3_APL + bk * 256 + 8 * (bnq & 1);                   // + (((bnq >> 1) + 8 q) ^ b_sw) * 16
+    const int a_wr = ar * X3_ARS + ((((akq >> 1) ^ (ar >> 2)) & 3) << 4) + 8 * (akq & 1);   // + 64 q * X3_ARS  (row + 64: same swizzle)
+    const int b_sw = ((bk & 3) << 2) | ((bk >> 1) & 1) | (((bk >> 2) & 1) << 1);
+    const int b_wr = 3 * X3_APL + bk * 256 + ((bnq ^ b_sw) << 4);
     auto stage = [&](int buf) {                           // split the four pieces in registers, three planes each
         unsigned char* base = lds + buf * X3_BUF;
 #pragma unroll
@@ -1136,22 +1140,23 @@ __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
             *reinterpret_cast<u32x2s*>(d + X3_APL) = u32x2s{s0.mid, s1.mid};
             *reinterpret_cast<u32x2s*>(d + 2 * X3_APL) = u32x2s{s0.lo, s1.lo};
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            f32x4v v = breg[q];
+        {
+            typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+            f32x4v v0 = breg[0], v1 = breg[1];
             if (!chunk_full) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = b_ok ? v[j] : 0.f;
+                for (int j = 0; j < 4; ++j) { v0[j] = b_ok ? v0[j] : 0.f; v1[j] = b_ok ? v1[j] : 0.f; }
             }
-            const Split3 s0 = split3_pair(v[0], v[1]), s1 = split3_pair(v[2], v[3]);
-            unsigned char* d = base + b_wr + ((((bnq >> 1) + 8 * q) ^ b_sw) << 4);
-            *reinterpret_cast<u32x2s*>(d) = u32x2s{s0.hi, s1.hi};
-            *reinterpret_cast<u32x2s*>(d + X3_BPL) = u32x2s{s0.mid, s1.mid};
-            *reinterpret_cast<u32x2s*>(d + 2 * X3_BPL) = u32x2s{s0.lo, s1.lo};
+            const Split3 s0 = split3_pair(v0[0], v0[1]), s1 = split3_pair(v0[2], v0[3]), s2 = split3_pair(v1[0], v1[1]), s3 = split3_pair(v1[2], v1[3]);
+            unsigned char* d = base + b_wr;
+            *reinterpret_cast<u32x4s*>(d) = u32x4s{s0.hi, s1.hi, s2.hi, s3.hi};
+            *reinterpret_cast<u32x4s*>(d + X3_BPL) = u32x4s{s0.mid, s1.mid, s2.mid, s3.mid};
+            *reinterpret_cast<u32x4s*>(d + 2 * X3_BPL) = u32x4s{s0.lo, s1.lo, s2.lo, s3.lo};
         }
     };
     // fragment addresses
-    const int a_rd = (wm * 64 + l31) * X3_ARS + 32 * h;                       // + i * 32 * X3_ARS + 16 * g + plane * X3_APL
+    const int a_rd = (wm * 64 + l31) * X3_ARS;                                // + i * 32 * X3_ARS + (slot ^ a_sw) * 16 + plane * X3_APL,  slot = 2h + g
+    const int a_sw = (l31 >> 2) & 3;                                         // ((row >> 2) & 3: the tile bases are multiples of 32)
     const int b_ch = wn * 4 + (g16 & 1) * 2 + (p4 >> 1);                     // 16-byte chunk of this lane's 4 columns
     const int b_rd = 3 * X3_APL + (16 * h + q4) * 256 + 8 * (p4 & 1);         // + (8 g + 4 hi) * 256 + (chunk ^ swizzle) * 16 + plane * X3_BPL
     if (kb < ke) {
@@ -1170,10 +1175,11 @@ __global__ __launch_bounds__(512) void dw_f32x3(GemmArgs g) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) A[i][pl] = *reinterpret_cast<const bf16x8*>(base + pl * X3_APL + a_rd + i * 32 * X3_ARS + 16 * g2);
+                for (int i = 0; i < 2; ++i) A[i][pl] = *reinterpret_cast<const bf16x8*>(base + pl * X3_APL + a_rd + i * 32 * X3_ARS + (((2 * h + g2) ^ a_sw) << 4));
                 const unsigned char* r0 = base + pl * X3_BPL + b_rd + 8 * g2 * 256;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + ((b_ch ^ ((q4 << 2) | ((2 * g2) & 3))) << 4)));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * 256 + ((b_ch ^ ((q4 << 2) | ((2 * g2 + 1) & 3))) << 4)));
+                // swizzle of k-row r = 16h + 8g + 4hi + q4:  ((r & 3) << 2) | ((r >> 1) & 1) | (((r >> 2) & 1) << 1)  =  (q4 << 2) | (q4 >> 1) | (hi << 1)
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + ((b_ch ^ ((q4 << 2) | (q4 >> 1))) << 4)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * 256 + ((b_ch ^ ((q4 << 2) | (q4 >> 1) | 2)) << 4)));
                 const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 B[pl] = __builtin_bit_cast(bf16x8, v);
             }
